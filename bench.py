@@ -1,0 +1,290 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the DEWI hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Metric: queries/s (plus p50 latency) of brute-force cosine kNN + DEWI re-rank over a
+1M x 768 fp32 corpus, query batch 1, k=10, eta=0.3 (BASELINE.json configs[1]).  One
+"step" = one query through the whole hot path: corpus scan with fused top-2k, select,
+blend, top-k.  Corpus, payload columns and queries are resident in HBM before the timed
+region; results stay on the device (the PCIe-inclusive API latency is reported
+separately as p50_latency_ms).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): the 1M-row corpus is
+sharded by contiguous doc-id range (strong scaling; `--scaling weak` keeps 1M rows per
+GPU = configs[3]); each step scans the local shard, all-gathers the per-shard top-2k
+records (16 B each) and merges them on every rank.  The all-gather of query i overlaps the
+scan of query i+1.
+
+The JSON line also carries
+  roofline      achieved HBM GB/s of the scan kernel (algorithmic bytes / mean kernel time
+                measured with hipEvents inside the timed region) against the 8 TB/s peak;
+  cpu_baseline  the NumPy oracle (a port of the reference's ExactIndex.search) timed on the
+                host cores of this box on a bounded sample of the same workload, used at the
+                same time as the parity gate for the GPU results (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent
+PKG_DIR = REPO / "dewi-design-for-an-entropy-weighted-index-for-text-image-corpora_amd"
+sys.path.insert(0, str(PKG_DIR))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--docs", type=int, default=1_000_000, help="corpus rows (total for strong, per GPU for weak)")
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--eta", type=float, default=0.3)
+    ap.add_argument("--batch", type=int, default=1, help="queries per step")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--cpu-queries", type=int, default=256, help="queries timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--latency-queries", type=int, default=200)
+    ap.add_argument("--scan-blocks", type=int, default=0)
+    ap.add_argument("--rows-per-iter", type=int, default=0)
+    ap.add_argument("--nontemporal", type=int, default=-1)
+    return ap.parse_args()
+
+
+def make_corpus(torch, n_rows, dim, seed, device):
+    """Unit-norm gaussian rows + payload columns, generated on the GPU (synthetic data with the
+    distributions of the reference's harness, scripts/profile_index.py:49-70)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    emb = torch.empty((n_rows, dim), dtype=torch.float32, device=device)
+    chunk = 131072
+    for s in range(0, n_rows, chunk):
+        e = min(n_rows, s + chunk)
+        emb[s:e] = torch.randn((e - s, dim), generator=g, device=device, dtype=torch.float32)
+    rs = np.random.RandomState(seed + 1000)
+    cols = {
+        "dewi": np.clip(rs.beta(2, 2, n_rows), 0, 1),
+        "ht_mean": rs.gamma(2, 0.5, n_rows),
+        "hi_mean": rs.gamma(2, 0.3, n_rows),
+    }
+    return emb, cols
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    device = torch.device(f"cuda:{local_rank}")
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    from dewi import _engine as eng
+    from dewi import _native as nat
+    nat.load_library()
+    eng.tuning(args.scan_blocks, args.rows_per_iter, args.nontemporal)
+
+    # ------------------------------------------------------------------ data, resident in HBM
+    if args.scaling == "strong":
+        total_rows = args.docs
+        lo = (total_rows * rank) // world
+        hi = (total_rows * (rank + 1)) // world
+        # every rank generates the same full stream and keeps its slice: identical to the 1-GPU corpus
+        full, cols = make_corpus(torch, total_rows, args.dim, 42, device)
+        emb_raw = full[lo:hi].clone() if world > 1 else full
+        del full
+        cols = {k: v[lo:hi] for k, v in cols.items()}
+    else:
+        total_rows = args.docs * world
+        lo, hi = args.docs * rank, args.docs * (rank + 1)
+        emb_raw, cols = make_corpus(torch, args.docs, args.dim, 42 + rank, device)
+    n_local = hi - lo
+    nat.check(nat.load_library().dewi_normalize_rows_f32(nat.ptr(emb_raw), nat.ptr(emb_raw), n_local, args.dim,
+                                                         nat.stream_ptr()))
+    c64 = [torch.from_numpy(np.ascontiguousarray(cols[k], dtype=np.float64)).to(device) for k in ("dewi", "ht_mean", "hi_mean")]
+    dewi32 = torch.empty(n_local, dtype=torch.float32, device=device)
+    ent32 = torch.empty(n_local, dtype=torch.float32, device=device)
+    nat.check(nat.load_library().dewi_payload_soa_f64(nat.ptr(c64[0]), nat.ptr(c64[1]), nat.ptr(c64[2]), nat.ptr(dewi32),
+                                                      nat.ptr(ent32), n_local, nat.stream_ptr()))
+    corpus = eng.DeviceCorpus(emb_raw, dewi32, ent32, "cosine", id_offset=lo)
+    n_q = args.warmup + args.steps
+    B = args.batch
+    qg = torch.Generator(device=device)
+    qg.manual_seed(7)
+    n_distinct = min(n_q, 4096)
+    Q = torch.randn((n_distinct, B, args.dim), generator=qg, device=device, dtype=torch.float32)
+    k, eta = args.k, args.eta
+    c = min(2 * k, total_rows)
+    out_ids = torch.empty((n_distinct, B, k), dtype=torch.int64, device=device)
+    out_sc = torch.empty((n_distinct, B, k), dtype=torch.float32, device=device)
+    torch.cuda.synchronize()
+
+    # ------------------------------------------------------------------ the step
+    if world == 1:
+        def run(first, count):
+            for i in range(first, first + count):
+                j = i % n_distinct
+                corpus.search_device(Q[j], k, eta, 0.0, out_ids[j], out_sc[j])
+    else:
+        depth = 4
+        send = [torch.empty((B, c, 4), dtype=torch.int32, device=device) for _ in range(depth)]
+        recv = [torch.empty((world, B, c, 4), dtype=torch.int32, device=device) for _ in range(depth)]
+
+        def run(first, count):
+            pending = None
+            for i in range(first, first + count):
+                j, s = i % n_distinct, i % depth
+                corpus.candidates_device(Q[j], c, send[s])
+                work = dist.all_gather_into_tensor(recv[s].view(-1), send[s].view(-1), async_op=True)
+                if pending is not None:
+                    pw, pj, ps = pending
+                    pw.wait()
+                    eng.merge_rerank_device(recv[ps], c, k, eta, 0.0, out_ids[pj], out_sc[pj])
+                pending = (work, j, s)
+            pw, pj, ps = pending
+            pw.wait()
+            eng.merge_rerank_device(recv[ps], c, k, eta, 0.0, out_ids[pj], out_sc[pj])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(0, args.warmup)
+    barrier()
+    eng.timing(True)
+    t0 = time.perf_counter()
+    run(args.warmup, args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    scan_ms, scan_launches = eng.timing_read()
+    eng.timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    qps = args.steps * B / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+    elem = corpus.emb.element_size()
+    algo_bytes = n_local * args.dim * elem + B * args.dim * 4           # per scan launch, this rank
+    achieved = algo_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    traffic = None
+    tfile = REPO / "profiles" / "hbm_traffic.json"
+    if tfile.exists():
+        try:
+            rec = json.loads(tfile.read_text())
+            key = f"{n_local}x{args.dim}x{elem}"
+            traffic = rec.get(key)
+        except Exception:  # noqa: BLE001
+            traffic = None
+
+    result = {
+        "metric": "queries/sec + p50 latency, 1M×768 corpus, k=10, η=0.3, at 1/2/4/8 GPUs",
+        "value": round(qps, 2),
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 5),
+        "higher_is_better": True,
+        "scaling": args.scaling,
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{total_rows} docs x d={args.dim} fp32, query batch={B}, k={k}, eta={eta}, "
+                               f"brute-force cosine kNN + DEWI re-rank (BASELINE.json configs[1])",
+                   "docs": total_rows, "dim": args.dim, "k": k, "eta": eta, "batch": B, "candidates": c,
+                   "parallelism": f"doc-id shards x{world}" if world > 1 else "single GPU",
+                   "rows_per_gpu": n_local},
+        "roofline": {"bound": "hbm", "kernel": "scan_rows_f32", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "algorithmic_bytes_per_launch": algo_bytes, "mean_kernel_ms": round(scan_ms, 5),
+                     "launches_timed": scan_launches},
+    }
+
+    # ------------------------------------------------------------------ p50 latency through the API
+    if rank == 0 and world == 1 and args.latency_queries > 0:
+        qh = Q[: args.latency_queries, 0].cpu().numpy()
+        lat = []
+        for j in range(min(args.latency_queries, qh.shape[0])):
+            t1 = time.perf_counter()
+            corpus.search(qh[j], k, eta, 0.0)
+            lat.append(time.perf_counter() - t1)
+        lat = np.array(lat[5:]) * 1e3
+        result["p50_latency_ms"] = round(float(np.percentile(lat, 50)), 4)
+        result["p99_latency_ms"] = round(float(np.percentile(lat, 99)), 4)
+
+    # ------------------------------------------------------------------ CPU baseline + parity gate (rank 0, N=1)
+    if rank == 0 and world == 1 and args.cpu_queries > 0:
+        sys.path.insert(0, str(REPO / "oracle"))
+        sys.path.insert(0, str(REPO / "tests"))
+        import dewi_oracle as orc           # checker / reported baseline only
+        from parity import compare_query
+        E = corpus.emb.cpu().numpy()
+        d32, e32 = dewi32.cpu().numpy(), ent32.cpu().numpy()
+        nq = min(args.cpu_queries, n_distinct)
+        qh = Q[:nq, 0].cpu().numpy()
+        gi = out_ids[:nq, 0].cpu().numpy() if n_q >= nq else None
+        gs = out_sc[:nq, 0].cpu().numpy()
+        for j in range(3):
+            orc.search(E, qh[j], d32, e32, k, eta, 0.0)
+        lat = []
+        ref = []
+        budget = time.perf_counter() + 30.0
+        for j in range(nq):
+            t1 = time.perf_counter()
+            ref.append(orc.search(E, qh[j], d32, e32, k, eta, 0.0))
+            lat.append(time.perf_counter() - t1)
+            if time.perf_counter() > budget:
+                break
+        lat = np.array(lat)
+        cores = os.cpu_count() or 1
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except Exception:  # noqa: BLE001
+            pass
+        result["cpu_baseline"] = {"value": round(len(lat) / float(lat.sum()), 2), "unit": "queries/s", "cores": cores,
+                                  "kind": "port", "p50_ms": round(float(np.percentile(lat, 50) * 1e3), 3),
+                                  "sample": f"{len(lat)} single queries of the same workload (full {total_rows}x{args.dim} "
+                                            f"corpus), NumPy/OpenBLAS oracle, all host cores"}
+        # parity gate: GPU results of the timed run vs the oracle on the same queries
+        checked = min(len(ref), 32)
+        bad, near = 0, 0
+        for j in range(checked):
+            decisive, msg = compare_query(E, qh[j], d32, e32, k, eta, 0.0, "cosine", gi[j], gs[j], exact_gaps=False)
+            near += 0 if decisive else 1
+            if msg is not None:
+                bad += 1
+                print(f"PARITY FAIL query {j}: {msg}", file=sys.stderr)
+        result["parity"] = {"queries_checked": checked, "mismatches": bad, "near_tie_excluded": near}
+        if bad:
+            print(json.dumps(result))
+            raise SystemExit("parity gate failed: the bench result is invalid")
+
+    if rank == 0:
+        print(json.dumps(result, ensure_ascii=False))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

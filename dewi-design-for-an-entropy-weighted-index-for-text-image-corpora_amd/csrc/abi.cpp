@@ -1,0 +1,370 @@
+// extern "C" boundary of the DEWI hot path (declared in include/dewi_hip.h).
+//
+// Nothing here touches torch: callers hand over device pointers, sizes and a hipStream_t.  The
+// functions validate arguments, carve the caller's workspace, choose launch shapes and enqueue
+// kernels; no allocation, no device synchronisation (except dewi_timing_read).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "launch.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+  return fail(DEWI_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+struct DeviceInfo {
+  bool ready = false;
+  int cus = 0;
+  int wave = 0;
+  size_t mem = 0;
+};
+DeviceInfo g_dev;
+std::mutex g_dev_mu;
+
+int ensure_device(DeviceInfo& out) {
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  if (!g_dev.ready) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
+    hipDeviceProp_t p;
+    e = hipGetDeviceProperties(&p, dev);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDeviceProperties");
+    g_dev.cus = p.multiProcessorCount;
+    g_dev.wave = p.warpSize;
+    g_dev.mem = p.totalGlobalMem;
+    if (g_dev.wave != 64) return fail(DEWI_ERR_UNSUPPORTED, "wavefront size %d: this library is written for gfx950 (wave64)", g_dev.wave);
+    g_dev.ready = true;
+  }
+  out = g_dev;
+  return DEWI_OK;
+}
+
+dewi::Tuning g_tuning{0, 0, -1};
+
+// ---- timing ring -----------------------------------------------------------------------------
+struct Timing {
+  bool enabled = false;
+  std::vector<hipEvent_t> start, stop;
+  size_t used = 0;
+} g_timing;
+std::mutex g_timing_mu;
+
+struct ScanTimer {
+  hipStream_t stream;
+  hipEvent_t stop = nullptr;
+  explicit ScanTimer(hipStream_t s) : stream(s) {
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    if (!g_timing.enabled) return;
+    if (g_timing.used == g_timing.start.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+      g_timing.start.push_back(a);
+      g_timing.stop.push_back(b);
+    }
+    (void)hipEventRecord(g_timing.start[g_timing.used], stream);
+    stop = g_timing.stop[g_timing.used];
+    ++g_timing.used;
+  }
+  ~ScanTimer() {
+    if (stop) (void)hipEventRecord(stop, stream);
+  }
+};
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct KnnLayout {
+  dewi::ScanPlan plan;
+  size_t keys_off, keys_bytes;
+  size_t qn_off, qn_bytes;
+  size_t total;
+};
+
+KnnLayout layout_knn(int64_t n_rows, int dim, int elem_bytes, int n_queries, int n_candidates, int cus) {
+  KnnLayout L;
+  L.plan = dewi::plan_scan(n_rows, dim, elem_bytes, n_candidates, cus, g_tuning);
+  L.keys_off = 0;
+  L.keys_bytes = align_up(static_cast<size_t>(n_queries) * static_cast<size_t>(L.plan.keys_per_query) * 8, 256);
+  L.qn_off = L.keys_off + L.keys_bytes;
+  L.qn_bytes = align_up(static_cast<size_t>(n_queries) * dim * 4, 256);
+  L.total = L.qn_off + L.qn_bytes;
+  return L;
+}
+
+dewi::RerankParams make_rerank(double eta, double pref) {
+  dewi::RerankParams rp;
+  // NumPy treats the Python floats (1 - eta), eta, entropy_pref as weak scalars: each is rounded to
+  // fp32 once and the array arithmetic stays fp32 (reference backends.py:461-465).
+  rp.w_sim = static_cast<float>(1.0 - eta);
+  rp.w_dewi = static_cast<float>(eta);
+  rp.w_ent = static_cast<float>(pref);
+  rp.use_ent = pref != 0.0 ? 1 : 0;
+  return rp;
+}
+
+// Steps 1-3 for every query: fills the keys region of the workspace.
+int run_scan(const KnnLayout& L, const void* d_E, int elem_type, int64_t n_rows, int dim, const float* d_Q,
+             int n_queries, int n_candidates, int space, char* ws, hipStream_t stream) {
+  uint64_t* keys = reinterpret_cast<uint64_t*>(ws + L.keys_off);
+  float* qn = reinterpret_cast<float*>(ws + L.qn_off);
+  hipError_t e;
+  if (elem_type != 0) return fail(DEWI_ERR_UNSUPPORTED, "bf16 corpus scan is not built yet");
+  if (!L.plan.fast) {
+    e = dewi::launch_prepare_queries(d_Q, qn, n_queries, dim, space, stream);
+    if (e != hipSuccess) return hip_fail(e, "prepare_queries");
+  }
+  ScanTimer timer(stream);
+  int q = 0;
+  while (q < n_queries) {
+    const int nq = (n_queries - q >= 4) ? 4 : 1;
+    e = dewi::launch_scan_f32(L.plan, static_cast<const float*>(d_E), n_rows, dim, d_Q, L.plan.fast ? nullptr : qn, q,
+                              nq, n_candidates, space, keys, stream);
+    if (e != hipSuccess) return hip_fail(e, "scan launch");
+    q += nq;
+  }
+  return DEWI_OK;
+}
+
+int check_common(const void* d_E, int64_t n_rows, int dim, const float* d_Q, int n_queries, int space) {
+  if (!d_E || !d_Q) return fail(DEWI_ERR_INVALID_ARG, "null embedding or query pointer");
+  if (n_rows <= 0) return fail(DEWI_ERR_INVALID_ARG, "n_rows must be positive (got %lld)", static_cast<long long>(n_rows));
+  if (n_rows > 0xFFFFFFFFll) return fail(DEWI_ERR_UNSUPPORTED, "n_rows %lld exceeds 2^32-1 rows per device", static_cast<long long>(n_rows));
+  if (dim <= 0) return fail(DEWI_ERR_INVALID_ARG, "dim must be positive (got %d)", dim);
+  if (n_queries <= 0) return fail(DEWI_ERR_INVALID_ARG, "n_queries must be positive (got %d)", n_queries);
+  if (space != DEWI_SPACE_COSINE && space != DEWI_SPACE_L2) return fail(DEWI_ERR_INVALID_ARG, "unknown space %d", space);
+  return DEWI_OK;
+}
+
+int knn_rerank_impl(const void* d_E, int elem_type, int64_t n_rows, int dim, const float* d_Q, int n_queries,
+                    const float* d_dewi32, const float* d_ent32, int k, double eta, double pref, int space,
+                    int64_t* d_out_ids, float* d_out_scores, void* d_ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  int rc = check_common(d_E, n_rows, dim, d_Q, n_queries, space);
+  if (rc) return rc;
+  if (k <= 0) return DEWI_OK;  // candidate_count <= 0 -> [] (reference backends.py:439-441)
+  if (k > n_rows)
+    return fail(DEWI_ERR_K_OUT_OF_BOUNDS, "kth(=%lld) out of bounds (%lld)", static_cast<long long>(n_rows - k),
+                static_cast<long long>(n_rows));
+  if (!d_dewi32 || !d_ent32 || !d_out_ids || !d_out_scores) return fail(DEWI_ERR_INVALID_ARG, "null payload or output pointer");
+  const int64_t c64 = (2ll * k < n_rows) ? 2ll * k : n_rows;
+  if (c64 > dewi::kMaxSortCandidates)
+    return fail(DEWI_ERR_UNSUPPORTED, "candidate count %lld (= min(2k, n_rows)) exceeds %d", static_cast<long long>(c64),
+                dewi::kMaxSortCandidates);
+  const int c = static_cast<int>(c64);
+  DeviceInfo dev;
+  rc = ensure_device(dev);
+  if (rc) return rc;
+  const KnnLayout L = layout_knn(n_rows, dim, elem_type ? 2 : 4, n_queries, c, dev.cus);
+  if (!d_ws || ws_bytes < L.total) return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, L.total);
+  char* ws = static_cast<char*>(d_ws);
+  rc = run_scan(L, d_E, elem_type, n_rows, dim, d_Q, n_queries, c, space, ws, stream);
+  if (rc) return rc;
+  const dewi::RerankParams rp = make_rerank(eta, pref);
+  hipError_t e = dewi::launch_select_rerank(reinterpret_cast<const uint64_t*>(ws + L.keys_off), L.plan.keys_per_query,
+                                            n_queries, c, k, rp, d_dewi32, d_ent32, 0, d_out_ids, d_out_scores, nullptr,
+                                            stream);
+  if (e != hipSuccess) return hip_fail(e, "select_rerank launch");
+  return DEWI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dewi_abi_version(void) { return DEWI_ABI_VERSION; }
+const char* dewi_last_error(void) { return g_err; }
+
+int dewi_device_info(int* out_compute_units, int* out_wavefront, size_t* out_total_mem) {
+  DeviceInfo d;
+  int rc = ensure_device(d);
+  if (rc) return rc;
+  if (out_compute_units) *out_compute_units = d.cus;
+  if (out_wavefront) *out_wavefront = d.wave;
+  if (out_total_mem) *out_total_mem = d.mem;
+  return DEWI_OK;
+}
+
+int dewi_normalize_rows_f32(const float* d_src, float* d_dst, int64_t n_rows, int dim, void* stream) {
+  if (n_rows < 0 || dim <= 0) return fail(DEWI_ERR_INVALID_ARG, "bad shape %lld x %d", static_cast<long long>(n_rows), dim);
+  if (n_rows == 0) return DEWI_OK;
+  if (!d_src || !d_dst) return fail(DEWI_ERR_INVALID_ARG, "null pointer");
+  hipError_t e = dewi::launch_normalize_rows(d_src, d_dst, n_rows, dim, static_cast<hipStream_t>(stream));
+  return e == hipSuccess ? DEWI_OK : hip_fail(e, "normalize_rows launch");
+}
+
+int dewi_convert_f32_to_bf16(const float* d_src, uint16_t* d_dst, int64_t n_elems, void* stream) {
+  if (n_elems < 0) return fail(DEWI_ERR_INVALID_ARG, "negative element count");
+  if (n_elems == 0) return DEWI_OK;
+  if (!d_src || !d_dst) return fail(DEWI_ERR_INVALID_ARG, "null pointer");
+  hipError_t e = dewi::launch_f32_to_bf16(d_src, d_dst, n_elems, static_cast<hipStream_t>(stream));
+  return e == hipSuccess ? DEWI_OK : hip_fail(e, "f32_to_bf16 launch");
+}
+
+int dewi_payload_soa_f64(const double* d_dewi, const double* d_ht_mean, const double* d_hi_mean, float* d_dewi32,
+                         float* d_ent32, int64_t n_rows, void* stream) {
+  if (n_rows < 0) return fail(DEWI_ERR_INVALID_ARG, "negative row count");
+  if (n_rows == 0) return DEWI_OK;
+  if (!d_dewi || !d_ht_mean || !d_hi_mean || !d_dewi32 || !d_ent32) return fail(DEWI_ERR_INVALID_ARG, "null pointer");
+  hipError_t e = dewi::launch_payload_soa(d_dewi, d_ht_mean, d_hi_mean, d_dewi32, d_ent32, n_rows,
+                                          static_cast<hipStream_t>(stream));
+  return e == hipSuccess ? DEWI_OK : hip_fail(e, "payload_soa launch");
+}
+
+size_t dewi_knn_workspace_bytes(int64_t n_rows, int dim, int n_queries, int n_candidates) {
+  DeviceInfo dev;
+  if (ensure_device(dev)) return 0;
+  if (n_rows <= 0 || dim <= 0 || n_queries <= 0 || n_candidates <= 0) return 0;
+  return layout_knn(n_rows, dim, 4, n_queries, n_candidates, dev.cus).total;
+}
+
+int dewi_knn_rerank_f32(const float* d_E, int64_t n_rows, int dim, const float* d_Q, int n_queries,
+                        const float* d_dewi32, const float* d_ent32, int k, double eta, double entropy_pref, int space,
+                        int64_t* d_out_ids, float* d_out_scores, void* d_workspace, size_t workspace_bytes,
+                        void* stream) {
+  return knn_rerank_impl(d_E, 0, n_rows, dim, d_Q, n_queries, d_dewi32, d_ent32, k, eta, entropy_pref, space,
+                         d_out_ids, d_out_scores, d_workspace, workspace_bytes, stream);
+}
+
+int dewi_knn_rerank_bf16(const uint16_t* d_E, int64_t n_rows, int dim, const float* d_Q, int n_queries,
+                         const float* d_dewi32, const float* d_ent32, int k, double eta, double entropy_pref, int space,
+                         int64_t* d_out_ids, float* d_out_scores, void* d_workspace, size_t workspace_bytes,
+                         void* stream) {
+  return knn_rerank_impl(d_E, 1, n_rows, dim, d_Q, n_queries, d_dewi32, d_ent32, k, eta, entropy_pref, space,
+                         d_out_ids, d_out_scores, d_workspace, workspace_bytes, stream);
+}
+
+int dewi_knn_candidates(const void* d_E, int elem_type, int64_t n_rows, int dim, const float* d_Q, int n_queries,
+                        const float* d_dewi32, const float* d_ent32, int n_candidates, int space, int64_t id_offset,
+                        dewi_candidate* d_out, void* d_workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  int rc = check_common(d_E, n_rows, dim, d_Q, n_queries, space);
+  if (rc) return rc;
+  if (n_candidates <= 0) return DEWI_OK;
+  if (n_candidates > dewi::kMaxSortCandidates)
+    return fail(DEWI_ERR_UNSUPPORTED, "n_candidates %d exceeds %d", n_candidates, dewi::kMaxSortCandidates);
+  if (!d_dewi32 || !d_ent32 || !d_out) return fail(DEWI_ERR_INVALID_ARG, "null payload or output pointer");
+  if (id_offset < 0 || id_offset + n_rows > 0x7FFFFFFFll)
+    return fail(DEWI_ERR_UNSUPPORTED, "global row ids must fit int32 (offset %lld + %lld rows)",
+                static_cast<long long>(id_offset), static_cast<long long>(n_rows));
+  DeviceInfo dev;
+  rc = ensure_device(dev);
+  if (rc) return rc;
+  // a shard can contribute at most n_rows candidates; the rest of each list is padding
+  const int c_local = n_candidates < n_rows ? n_candidates : static_cast<int>(n_rows);
+  const KnnLayout L = layout_knn(n_rows, dim, elem_type ? 2 : 4, n_queries, c_local, dev.cus);
+  if (!d_workspace || workspace_bytes < L.total)
+    return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, L.total);
+  char* ws = static_cast<char*>(d_workspace);
+  rc = run_scan(L, d_E, elem_type, n_rows, dim, d_Q, n_queries, c_local, space, ws, stream);
+  if (rc) return rc;
+  dewi::RerankParams rp = make_rerank(0.0, 0.0);
+  // The select kernel writes n_candidates records per query; when the shard has fewer rows than
+  // that, it selects every row and pads the tail (id = -1, sim = -inf).
+  hipError_t e = dewi::launch_select_rerank(reinterpret_cast<const uint64_t*>(ws + L.keys_off), L.plan.keys_per_query,
+                                            n_queries, n_candidates, 0, rp, d_dewi32, d_ent32, id_offset, nullptr,
+                                            nullptr, d_out, stream);
+  if (e != hipSuccess) return hip_fail(e, "select (candidates) launch");
+  return DEWI_OK;
+}
+
+int dewi_merge_rerank(const dewi_candidate* d_lists, int n_lists, int n_queries, int list_len, int n_candidates, int k,
+                      double eta, double entropy_pref, int64_t* d_out_ids, float* d_out_scores, void* stream) {
+  if (!d_lists || !d_out_ids || !d_out_scores) return fail(DEWI_ERR_INVALID_ARG, "null pointer");
+  if (n_lists <= 0 || n_queries <= 0 || list_len <= 0 || n_candidates <= 0)
+    return fail(DEWI_ERR_INVALID_ARG, "non-positive size");
+  if (k <= 0) return DEWI_OK;
+  if (k > n_candidates) return fail(DEWI_ERR_K_OUT_OF_BOUNDS, "k %d exceeds candidate count %d", k, n_candidates);
+  if (static_cast<int64_t>(n_lists) * list_len > dewi::kMaxSortCandidates)
+    return fail(DEWI_ERR_UNSUPPORTED, "n_lists*list_len = %lld exceeds %d", static_cast<long long>(n_lists) * list_len,
+                dewi::kMaxSortCandidates);
+  hipError_t e = dewi::launch_merge_rerank(d_lists, n_lists, n_queries, list_len, n_candidates, k,
+                                           make_rerank(eta, entropy_pref), d_out_ids, d_out_scores,
+                                           static_cast<hipStream_t>(stream));
+  return e == hipSuccess ? DEWI_OK : hip_fail(e, "merge_rerank launch");
+}
+
+size_t dewi_robust_fit_workspace_bytes(int n_signals) {
+  return n_signals > 0 ? dewi::robust_fit_workspace_bytes(n_signals) : 0;
+}
+
+int dewi_robust_fit_f32(const float* d_S, int64_t n, int64_t ld, int n_signals, float* d_med, float* d_mad,
+                        void* d_workspace, size_t workspace_bytes, void* stream) {
+  if (!d_S || !d_med || !d_mad) return fail(DEWI_ERR_INVALID_ARG, "null pointer");
+  if (n <= 0 || n_signals <= 0 || ld < n) return fail(DEWI_ERR_INVALID_ARG, "bad shape n=%lld ld=%lld n_signals=%d",
+                                                      static_cast<long long>(n), static_cast<long long>(ld), n_signals);
+  if (n > 0xFFFFFFFFll) return fail(DEWI_ERR_UNSUPPORTED, "n exceeds 2^32-1");
+  const size_t need = dewi::robust_fit_workspace_bytes(n_signals);
+  if (!d_workspace || workspace_bytes < need) return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, need);
+  hipError_t e = dewi::launch_robust_fit(d_S, n, ld, n_signals, d_med, d_mad, d_workspace, static_cast<hipStream_t>(stream));
+  return e == hipSuccess ? DEWI_OK : hip_fail(e, "robust_fit launch");
+}
+
+int dewi_score_f64(const void* d_S, int signals_are_f64, int64_t n, int64_t ld, const double* med, const double* mad,
+                   const double* weights, double delta, int mode, double* d_out, float* d_out32, void* stream) {
+  if (!d_S || !med || !mad || !weights || !d_out) return fail(DEWI_ERR_INVALID_ARG, "null pointer");
+  if (n < 0 || ld < n) return fail(DEWI_ERR_INVALID_ARG, "bad shape n=%lld ld=%lld", static_cast<long long>(n), static_cast<long long>(ld));
+  if (mode != DEWI_MODE_STANDARD && mode != DEWI_MODE_CONDITIONAL) return fail(DEWI_ERR_INVALID_ARG, "unknown mode %d", mode);
+  if (n == 0) return DEWI_OK;
+  dewi::ScoreParams sp;
+  for (int s = 0; s < DEWI_NUM_SIGNALS; ++s) {
+    sp.med[s] = med[s];
+    sp.scale[s] = 1.4826 * mad[s];  // reference scorer.py:31 — the product is rounded before the division
+  }
+  for (int i = 0; i < 5; ++i) sp.w[i] = weights[i];
+  sp.delta = delta;
+  sp.mode = mode;
+  hipError_t e = dewi::launch_score(d_S, signals_are_f64, n, ld, sp, d_out, d_out32, static_cast<hipStream_t>(stream));
+  return e == hipSuccess ? DEWI_OK : hip_fail(e, "score launch");
+}
+
+int dewi_timing_enable(int enable) {
+  std::lock_guard<std::mutex> lk(g_timing_mu);
+  g_timing.enabled = enable != 0;
+  g_timing.used = 0;
+  return DEWI_OK;
+}
+
+int dewi_timing_read(double* out_mean_scan_ms, int* out_launches) {
+  std::lock_guard<std::mutex> lk(g_timing_mu);
+  double total = 0.0;
+  int n = 0;
+  for (size_t i = 0; i < g_timing.used; ++i) {
+    hipError_t e = hipEventSynchronize(g_timing.stop[i]);
+    if (e != hipSuccess) return hip_fail(e, "hipEventSynchronize");
+    float ms = 0.f;
+    e = hipEventElapsedTime(&ms, g_timing.start[i], g_timing.stop[i]);
+    if (e != hipSuccess) return hip_fail(e, "hipEventElapsedTime");
+    total += ms;
+    ++n;
+  }
+  g_timing.used = 0;
+  if (out_mean_scan_ms) *out_mean_scan_ms = n ? total / n : 0.0;
+  if (out_launches) *out_launches = n;
+  return DEWI_OK;
+}
+
+int dewi_tuning_set(int scan_blocks, int rows_per_iter, int nontemporal) {
+  g_tuning.scan_blocks = scan_blocks;
+  g_tuning.rows_per_iter = rows_per_iter;
+  g_tuning.nontemporal = nontemporal;
+  return DEWI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,114 @@
+// Bulk ingest kernels for gfx950: row normalisation, bf16 rounding, payload SoA.
+//
+// Replaces the per-row work of ExactIndex.add (reference src/dewi/backends.py:403-406:
+// `emb = emb.astype(float32); emb = emb / np.linalg.norm(emb)`) and the per-candidate payload
+// reads of ExactIndex.search (:450-458).  All three are one-pass, HBM-bound elementwise kernels
+// (bytes = what they read + what they write).
+#include "common.hpp"
+#include "launch.hpp"
+
+namespace dewi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// One wavefront per row; the row is read twice (second read hits L1/L2: a 768-float row is 3 KiB).
+template <int VEC>
+__global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                             int64_t n_rows, int dim) {
+  const int lane = lane_id();
+  const int64_t gwave = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+  for (int64_t row = gwave; row < n_rows; row += n_waves) {
+    const float* s = src + row * dim;
+    float* d = dst + row * dim;
+    float ss = 0.f;
+    if constexpr (VEC == 4) {
+      const f32x4* sv = reinterpret_cast<const f32x4*>(s);
+      for (int u = lane; u < dim / 4; u += kWave) {
+        const f32x4 v = sv[u];
+        ss = __builtin_fmaf(v.x, v.x, ss);
+        ss = __builtin_fmaf(v.y, v.y, ss);
+        ss = __builtin_fmaf(v.z, v.z, ss);
+        ss = __builtin_fmaf(v.w, v.w, ss);
+      }
+    } else {
+      for (int j = lane; j < dim; j += kWave) ss = __builtin_fmaf(s[j], s[j], ss);
+    }
+    const float norm = __fsqrt_rn(wave_sum_f32(ss));
+    // no zero-norm guard, like the reference: 0/0 -> NaN
+    if constexpr (VEC == 4) {
+      const f32x4* sv = reinterpret_cast<const f32x4*>(s);
+      f32x4* dv = reinterpret_cast<f32x4*>(d);
+      for (int u = lane; u < dim / 4; u += kWave) {
+        f32x4 v = sv[u];
+        v.x = __fdiv_rn(v.x, norm);
+        v.y = __fdiv_rn(v.y, norm);
+        v.z = __fdiv_rn(v.z, norm);
+        v.w = __fdiv_rn(v.w, norm);
+        dv[u] = v;
+      }
+    } else {
+      for (int j = lane; j < dim; j += kWave) d[j] = __fdiv_rn(s[j], norm);
+    }
+  }
+}
+
+hipError_t launch_normalize_rows(const float* d_src, float* d_dst, int64_t n_rows, int dim, hipStream_t stream) {
+  if (n_rows <= 0) return hipSuccess;
+  int64_t blocks = (n_rows + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  const bool vec = dim % 4 == 0 && (reinterpret_cast<uintptr_t>(d_src) % 16 == 0) &&
+                   (reinterpret_cast<uintptr_t>(d_dst) % 16 == 0);
+  if (vec)
+    hipLaunchKernelGGL(normalize_rows_kernel<4>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, d_src,
+                       d_dst, n_rows, dim);
+  else
+    hipLaunchKernelGGL(normalize_rows_kernel<1>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, d_src,
+                       d_dst, n_rows, dim);
+  return hipGetLastError();
+}
+
+// fp32 -> bf16, round to nearest even; NaN stays NaN (quiet bit forced).
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+  const uint32_t u = __float_as_uint(f);
+  if (f != f) return static_cast<uint16_t>((u >> 16) | 0x0040u);
+  return static_cast<uint16_t>((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst,
+                                                          int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride)
+    dst[i] = f32_to_bf16_rne(src[i]);
+}
+
+hipError_t launch_f32_to_bf16(const float* d_src, uint16_t* d_dst, int64_t n, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, d_src, d_dst, n);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void payload_soa_kernel(const double* __restrict__ dewi,
+                                                          const double* __restrict__ ht,
+                                                          const double* __restrict__ hi, float* __restrict__ dewi32,
+                                                          float* __restrict__ ent32, int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    dewi32[i] = static_cast<float>(dewi[i]);
+    ent32[i] = static_cast<float>(__dmul_rn(__dadd_rn(ht[i], hi[i]), 0.5));
+  }
+}
+
+hipError_t launch_payload_soa(const double* dewi, const double* ht, const double* hi, float* dewi32, float* ent32,
+                              int64_t n, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(payload_soa_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, dewi, ht, hi,
+                     dewi32, ent32, n);
+  return hipGetLastError();
+}
+
+}  // namespace dewi

@@ -1,0 +1,425 @@
+// Corpus scan: similarity of every embedding row against a small group of queries, fused with a
+// streaming top-c selection, for gfx950 (MI355X).
+//
+// Replaces steps 1-3 of ExactIndex.search (reference src/dewi/backends.py:420-444):
+//   q <- q/||q||;  scores = E @ q  (or -sum((E-q)^2));  argpartition(scores, -c)[-c:]
+// The N-long score vector is never written: each wavefront keeps the best c keys it has seen in
+// registers (one 64-bit key per lane per slot) and only those leave the kernel.
+//
+// Roofline: HBM.  Algorithmic bytes per launch = n_rows * dim * sizeof(elem) (the corpus, read
+// exactly once) + n_queries*dim*4; nothing else is proportional to n_rows.
+//
+// Data movement (fast path, dim = 256*U floats): one wavefront owns one row at a time; lane l
+// issues U global_load_dwordx4 at byte offsets 16*l + 1024*u of the row, so every wave-instruction
+// reads 1 KiB contiguous and a row is U such instructions.  R rows (R*U loads) are issued
+// back-to-back before the first FMA, which keeps R*U KiB per wave in flight; consecutive waves of
+// the whole grid take consecutive R-row groups, so one sweep of the grid reads one contiguous
+// span of the matrix.  Query fragments live in registers for the whole kernel (the same 4*U
+// floats per lane are needed for every row), so there is no LDS traffic at all; the cross-lane
+// sum runs on the DPP crossbar.
+#include "common.hpp"
+#include "launch.hpp"
+
+namespace dewi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kSlots = kMaxListCandidates / kWave;  // 4 key registers per lane per query
+
+template <bool NT>
+__device__ __forceinline__ f32x4 load_x4(const f32x4* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  return *p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-wave top-c list.  Position p = slot*64 + lane is active when p < c.  `thr` is the smallest
+// active key (the entry a better candidate replaces), `thr_s` its score for the cheap test.
+// ---------------------------------------------------------------------------------------------
+struct WaveList {
+  uint64_t key[kSlots];
+  uint64_t thr;
+  float thr_s;
+
+  __device__ __forceinline__ void init(int c, int lane) {
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) key[s] = (s * kWave + lane) < c ? kKeyEmpty : kKeyInactive;
+    thr = kKeyEmpty;
+    thr_s = -__builtin_inff();
+  }
+  // `score` and `row` are wave-uniform.
+  __device__ __forceinline__ void offer(float score, uint32_t row, int lane) {
+    if (score < thr_s) return;  // common case; false for NaN so NaN rows reach the exact test
+    const uint64_t k = make_key(score, row);
+    if (k <= thr) return;
+    bool placed = false;
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) {
+      const unsigned long long m = __ballot(key[s] == thr);
+      if (!placed && m != 0ull) {
+        if (lane == __ffsll(m) - 1) key[s] = k;
+        placed = true;
+      }
+    }
+    uint64_t local = key[0];
+#pragma unroll
+    for (int s = 1; s < kSlots; ++s) local = key[s] < local ? key[s] : local;
+    thr = wave_min_u64(local);
+    thr_s = thr == kKeyEmpty ? -__builtin_inff() : key_score(thr);
+  }
+  __device__ __forceinline__ void store(uint64_t* dst, int c, int lane) const {
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) {
+      const int p = s * kWave + lane;
+      if (p < c) dst[p] = key[s];
+    }
+  }
+};
+
+template <int SPACE>
+__device__ __forceinline__ float accum4(f32x4 e, f32x4 q, float acc) {
+  if constexpr (SPACE == DEWI_SPACE_COSINE) {
+    acc = __builtin_fmaf(e.x, q.x, acc);
+    acc = __builtin_fmaf(e.y, q.y, acc);
+    acc = __builtin_fmaf(e.z, q.z, acc);
+    acc = __builtin_fmaf(e.w, q.w, acc);
+  } else {
+    float d;
+    d = e.x - q.x; acc = __builtin_fmaf(d, d, acc);
+    d = e.y - q.y; acc = __builtin_fmaf(d, d, acc);
+    d = e.z - q.z; acc = __builtin_fmaf(d, d, acc);
+    d = e.w - q.w; acc = __builtin_fmaf(d, d, acc);
+  }
+  return acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fast path: dim == 256*U, one row per wavefront step, R rows per iteration, NQ queries per pass.
+// ---------------------------------------------------------------------------------------------
+template <int U, int R, int NQ, int SPACE, bool DENSE, bool NT>
+__global__ __launch_bounds__(kScanThreads) void scan_rows_f32(const float* __restrict__ E, int64_t n_rows,
+                                                              const float* __restrict__ Q, int n_candidates,
+                                                              uint64_t* __restrict__ keys,
+                                                              int64_t keys_per_query) {
+  constexpr int D4 = 64 * U;  // float4 units per row
+  const int lane = lane_id();
+  const int wave_in_block = static_cast<int>(threadIdx.x) >> 6;
+  const int64_t gwave = static_cast<int64_t>(blockIdx.x) * (kScanThreads / kWave) + wave_in_block;
+  const int64_t n_waves = static_cast<int64_t>(gridDim.x) * (kScanThreads / kWave);
+
+  // Query fragments; cosine queries are normalised here (reference backends.py:420-424:
+  // divide by the norm unless it is zero).  Every wave repeats the same arithmetic, so all
+  // waves hold identical bits.
+  f32x4 qf[NQ][U];
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) {
+    const f32x4* qp = reinterpret_cast<const f32x4*>(Q) + static_cast<int64_t>(qi) * D4 + lane;
+#pragma unroll
+    for (int u = 0; u < U; ++u) qf[qi][u] = qp[u * 64];
+    if constexpr (SPACE == DEWI_SPACE_COSINE) {
+      float ss = 0.f;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        ss = __builtin_fmaf(qf[qi][u].x, qf[qi][u].x, ss);
+        ss = __builtin_fmaf(qf[qi][u].y, qf[qi][u].y, ss);
+        ss = __builtin_fmaf(qf[qi][u].z, qf[qi][u].z, ss);
+        ss = __builtin_fmaf(qf[qi][u].w, qf[qi][u].w, ss);
+      }
+      const float norm = __fsqrt_rn(wave_sum_f32(ss));
+      if (norm > 0.f) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          qf[qi][u].x = __fdiv_rn(qf[qi][u].x, norm);
+          qf[qi][u].y = __fdiv_rn(qf[qi][u].y, norm);
+          qf[qi][u].z = __fdiv_rn(qf[qi][u].z, norm);
+          qf[qi][u].w = __fdiv_rn(qf[qi][u].w, norm);
+        }
+      }
+    }
+  }
+
+  WaveList lst[DENSE ? 1 : NQ];
+  if constexpr (!DENSE) {
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) lst[qi].init(n_candidates, lane);
+  }
+
+  const f32x4* Ev = reinterpret_cast<const f32x4*>(E);
+  auto consume = [&](const f32x4(&v)[U], int64_t row) {
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+      float acc = 0.f;
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc = accum4<SPACE>(v[u], qf[qi][u], acc);
+      float s = wave_sum_f32(acc);
+      if constexpr (SPACE == DEWI_SPACE_L2) s = -s;
+      if constexpr (DENSE) {
+        if (lane == 0) keys[qi * keys_per_query + row] = make_key(s, static_cast<uint32_t>(row));
+      } else {
+        lst[qi].offer(s, static_cast<uint32_t>(row), lane);
+      }
+    }
+  };
+
+  // Full R-row groups.
+  const int64_t n_groups = n_rows / R;
+  for (int64_t g = gwave; g < n_groups; g += n_waves) {
+    const int64_t row0 = g * R;
+    f32x4 v[R][U];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const f32x4* p = Ev + (row0 + r) * D4 + lane;
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[r][u] = load_x4<NT>(p + u * 64);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) consume(v[r], row0 + r);
+  }
+  // Remainder rows (fewer than R), one per wave.
+  for (int64_t row = n_groups * R + gwave; row < n_rows; row += n_waves) {
+    f32x4 v[U];
+    const f32x4* p = Ev + row * D4 + lane;
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = load_x4<NT>(p + u * 64);
+    consume(v, row);
+  }
+
+  if constexpr (!DENSE) {
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi)
+      lst[qi].store(keys + qi * keys_per_query + gwave * n_candidates, n_candidates, lane);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic path: any dim.  G (power of two <= 64) lanes share a row, a wave covers 64/G rows per
+// step; queries come pre-normalised from global memory (L1/L2 resident).  VEC = 4 when rows can
+// be read as float4 (dim % 4 == 0, 16-byte aligned base), else scalar loads.
+// ---------------------------------------------------------------------------------------------
+template <int VEC>
+struct VecT;
+template <>
+struct VecT<1> { using type = float; };
+template <>
+struct VecT<4> { using type = f32x4; };
+
+template <int VEC, int NQ, int SPACE, bool DENSE>
+__global__ __launch_bounds__(kScanThreads) void scan_generic_f32(const float* __restrict__ E, int64_t n_rows, int dim,
+                                                                 const float* __restrict__ Qn, int group,
+                                                                 int n_candidates, uint64_t* __restrict__ keys,
+                                                                 int64_t keys_per_query) {
+  using V = typename VecT<VEC>::type;
+  const int lane = lane_id();
+  const int wave_in_block = static_cast<int>(threadIdx.x) >> 6;
+  const int64_t gwave = static_cast<int64_t>(blockIdx.x) * (kScanThreads / kWave) + wave_in_block;
+  const int64_t n_waves = static_cast<int64_t>(gridDim.x) * (kScanThreads / kWave);
+  const int rows_per_step = kWave / group;
+  const int sub = lane / group;  // which row of the step
+  const int lg = lane % group;   // position inside the row group
+  const int units = dim / VEC;
+
+  WaveList lst[DENSE ? 1 : NQ];
+  if constexpr (!DENSE) {
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) lst[qi].init(n_candidates, lane);
+  }
+
+  const int64_t n_steps = (n_rows + rows_per_step - 1) / rows_per_step;
+  for (int64_t st = gwave; st < n_steps; st += n_waves) {
+    const int64_t row = st * rows_per_step + sub;
+    float acc[NQ];
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) acc[qi] = 0.f;
+    if (row < n_rows) {
+      const V* ep = reinterpret_cast<const V*>(E + row * dim);
+      for (int u = lg; u < units; u += group) {
+        const V e = ep[u];
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) {
+          const V q = reinterpret_cast<const V*>(Qn + static_cast<int64_t>(qi) * dim)[u];
+          if constexpr (VEC == 4) {
+            acc[qi] = accum4<SPACE>(e, q, acc[qi]);
+          } else {
+            if constexpr (SPACE == DEWI_SPACE_COSINE) {
+              acc[qi] = __builtin_fmaf(e, q, acc[qi]);
+            } else {
+              const float d = e - q;
+              acc[qi] = __builtin_fmaf(d, d, acc[qi]);
+            }
+          }
+        }
+      }
+    }
+    // butterfly inside each group of `group` lanes
+    for (int off = group >> 1; off > 0; off >>= 1) {
+#pragma unroll
+      for (int qi = 0; qi < NQ; ++qi) acc[qi] += __shfl_xor(acc[qi], off, kWave);
+    }
+    for (int r = 0; r < rows_per_step; ++r) {
+      const int64_t rr = st * rows_per_step + r;
+      if (rr >= n_rows) break;
+#pragma unroll
+      for (int qi = 0; qi < NQ; ++qi) {
+        float s = __shfl(acc[qi], r * group, kWave);
+        if constexpr (SPACE == DEWI_SPACE_L2) s = -s;
+        if constexpr (DENSE) {
+          if (lane == 0) keys[qi * keys_per_query + rr] = make_key(s, static_cast<uint32_t>(rr));
+        } else {
+          lst[qi].offer(s, static_cast<uint32_t>(rr), lane);
+        }
+      }
+    }
+  }
+  if constexpr (!DENSE) {
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi)
+      lst[qi].store(keys + qi * keys_per_query + gwave * n_candidates, n_candidates, lane);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Query preparation for the generic path: one wave per query, cosine -> q / ||q|| unless 0.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWave) void prepare_queries_f32(const float* __restrict__ Q, float* __restrict__ Qn,
+                                                             int dim, int space) {
+  const int lane = lane_id();
+  const float* q = Q + static_cast<int64_t>(blockIdx.x) * dim;
+  float* o = Qn + static_cast<int64_t>(blockIdx.x) * dim;
+  float norm = 1.f;
+  bool scale = false;
+  if (space == DEWI_SPACE_COSINE) {
+    float ss = 0.f;
+    for (int j = lane; j < dim; j += kWave) ss = __builtin_fmaf(q[j], q[j], ss);
+    norm = __fsqrt_rn(wave_sum_f32(ss));
+    scale = norm > 0.f;
+  }
+  for (int j = lane; j < dim; j += kWave) o[j] = scale ? __fdiv_rn(q[j], norm) : q[j];
+}
+
+hipError_t launch_prepare_queries(const float* d_q, float* d_qn, int n_queries, int dim, int space,
+                                  hipStream_t stream) {
+  hipLaunchKernelGGL(prepare_queries_f32, dim3(n_queries), dim3(kWave), 0, stream, d_q, d_qn, dim, space);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Planner + dispatch
+// ---------------------------------------------------------------------------------------------
+static int next_pow2(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+ScanPlan plan_scan(int64_t n_rows, int dim, int elem_bytes, int n_candidates, int compute_units,
+                   const Tuning& tuning) {
+  ScanPlan p{};
+  (void)elem_bytes;
+  const int u = dim / 256;
+  p.fast = (dim % 256 == 0) && (u == 1 || u == 2 || u == 3 || u == 4 || u == 6);
+  p.dense = n_candidates > kMaxListCandidates;
+  p.vec = (dim % 4 == 0) ? 4 : 1;
+  p.group = p.fast ? kWave : (next_pow2((dim + p.vec - 1) / p.vec) > kWave ? kWave : next_pow2((dim + p.vec - 1) / p.vec));
+  p.rows_per_iter = p.fast ? (u <= 3 ? 4 : 2) : kWave / p.group;
+  if (p.fast && tuning.rows_per_iter > 0) p.rows_per_iter = tuning.rows_per_iter;
+  p.nontemporal = tuning.nontemporal < 0 ? true : tuning.nontemporal != 0;
+  // Enough workgroups to fill every CU several times over, but never more waves than there are
+  // row groups to give each wave at least four iterations of work.
+  int64_t max_blocks = static_cast<int64_t>(compute_units) * 8;
+  if (tuning.scan_blocks > 0) max_blocks = tuning.scan_blocks;
+  const int64_t rows_per_wave_iter = p.rows_per_iter;
+  const int64_t groups = (n_rows + rows_per_wave_iter - 1) / rows_per_wave_iter;
+  int64_t blocks = (groups + 4 * (kScanThreads / kWave) - 1) / (4 * (kScanThreads / kWave));
+  if (blocks < 1) blocks = 1;
+  if (blocks > max_blocks) blocks = max_blocks;
+  p.blocks = static_cast<int>(blocks);
+  p.waves = p.blocks * (kScanThreads / kWave);
+  p.nq_per_launch = 4;
+  p.keys_per_query = p.dense ? n_rows : static_cast<int64_t>(p.waves) * n_candidates;
+  return p;
+}
+
+template <int U, int R, int NQ, int SPACE, bool DENSE>
+static void launch_fast_nt(const ScanPlan& plan, const float* E, int64_t n_rows, const float* Q, int c,
+                           uint64_t* keys, hipStream_t stream) {
+  if (plan.nontemporal)
+    hipLaunchKernelGGL((scan_rows_f32<U, R, NQ, SPACE, DENSE, true>), dim3(plan.blocks), dim3(kScanThreads), 0,
+                       stream, E, n_rows, Q, c, keys, plan.keys_per_query);
+  else
+    hipLaunchKernelGGL((scan_rows_f32<U, R, NQ, SPACE, DENSE, false>), dim3(plan.blocks), dim3(kScanThreads), 0,
+                       stream, E, n_rows, Q, c, keys, plan.keys_per_query);
+}
+
+template <int U, int NQ, int SPACE, bool DENSE>
+static bool launch_fast_r(const ScanPlan& plan, const float* E, int64_t n_rows, const float* Q, int c,
+                          uint64_t* keys, hipStream_t stream) {
+  switch (plan.rows_per_iter) {
+    case 2: launch_fast_nt<U, 2, NQ, SPACE, DENSE>(plan, E, n_rows, Q, c, keys, stream); return true;
+    case 4:
+      if constexpr (U <= 3) { launch_fast_nt<U, 4, NQ, SPACE, DENSE>(plan, E, n_rows, Q, c, keys, stream); return true; }
+      return false;
+    case 8:
+      if constexpr (U <= 3 && NQ == 1 && !DENSE) { launch_fast_nt<U, 8, NQ, SPACE, DENSE>(plan, E, n_rows, Q, c, keys, stream); return true; }
+      return false;
+    default: return false;
+  }
+}
+
+template <int NQ, int SPACE, bool DENSE>
+static bool launch_fast_u(const ScanPlan& plan, int dim, const float* E, int64_t n_rows, const float* Q, int c,
+                          uint64_t* keys, hipStream_t stream) {
+  switch (dim / 256) {
+    case 1: return launch_fast_r<1, NQ, SPACE, DENSE>(plan, E, n_rows, Q, c, keys, stream);
+    case 2: return launch_fast_r<2, NQ, SPACE, DENSE>(plan, E, n_rows, Q, c, keys, stream);
+    case 3: return launch_fast_r<3, NQ, SPACE, DENSE>(plan, E, n_rows, Q, c, keys, stream);
+    case 4: return launch_fast_r<4, NQ, SPACE, DENSE>(plan, E, n_rows, Q, c, keys, stream);
+    case 6: return launch_fast_r<6, NQ, SPACE, DENSE>(plan, E, n_rows, Q, c, keys, stream);
+    default: return false;
+  }
+}
+
+template <int NQ, int SPACE, bool DENSE>
+static void launch_generic(const ScanPlan& plan, int dim, const float* E, int64_t n_rows, const float* Qn, int c,
+                           uint64_t* keys, hipStream_t stream) {
+  if (plan.vec == 4)
+    hipLaunchKernelGGL((scan_generic_f32<4, NQ, SPACE, DENSE>), dim3(plan.blocks), dim3(kScanThreads), 0, stream, E,
+                       n_rows, dim, Qn, plan.group, c, keys, plan.keys_per_query);
+  else
+    hipLaunchKernelGGL((scan_generic_f32<1, NQ, SPACE, DENSE>), dim3(plan.blocks), dim3(kScanThreads), 0, stream, E,
+                       n_rows, dim, Qn, plan.group, c, keys, plan.keys_per_query);
+}
+
+template <int NQ, int SPACE, bool DENSE>
+static hipError_t launch_scan_impl(const ScanPlan& plan, const float* E, int64_t n_rows, int dim, const float* Qraw,
+                                   const float* Qn, int c, uint64_t* keys, hipStream_t stream) {
+  if (plan.fast) {
+    if (!launch_fast_u<NQ, SPACE, DENSE>(plan, dim, E, n_rows, Qraw, c, keys, stream)) return hipErrorInvalidValue;
+  } else {
+    launch_generic<NQ, SPACE, DENSE>(plan, dim, E, n_rows, Qn, c, keys, stream);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_scan_f32(const ScanPlan& plan, const float* d_E, int64_t n_rows, int dim, const float* d_q_raw,
+                           const float* d_q_norm, int q0, int nq, int n_candidates, int space, uint64_t* d_keys,
+                           hipStream_t stream) {
+  const float* qr = d_q_raw + static_cast<int64_t>(q0) * dim;
+  const float* qn = d_q_norm ? d_q_norm + static_cast<int64_t>(q0) * dim : nullptr;
+  uint64_t* keys = d_keys + static_cast<int64_t>(q0) * plan.keys_per_query;
+#define DEWI_DISPATCH(NQ)                                                                                            \
+  if (space == DEWI_SPACE_COSINE)                                                                                    \
+    return plan.dense ? launch_scan_impl<NQ, DEWI_SPACE_COSINE, true>(plan, d_E, n_rows, dim, qr, qn, n_candidates, keys, stream)  \
+                      : launch_scan_impl<NQ, DEWI_SPACE_COSINE, false>(plan, d_E, n_rows, dim, qr, qn, n_candidates, keys, stream); \
+  else                                                                                                               \
+    return plan.dense ? launch_scan_impl<NQ, DEWI_SPACE_L2, true>(plan, d_E, n_rows, dim, qr, qn, n_candidates, keys, stream)      \
+                      : launch_scan_impl<NQ, DEWI_SPACE_L2, false>(plan, d_E, n_rows, dim, qr, qn, n_candidates, keys, stream);
+  if (nq == 1) {
+    DEWI_DISPATCH(1)
+  } else if (nq == 4) {
+    DEWI_DISPATCH(4)
+  }
+#undef DEWI_DISPATCH
+  return hipErrorInvalidValue;
+}
+
+}  // namespace dewi

@@ -1,0 +1,88 @@
+// Host-side launch declarations shared by abi.cpp and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/dewi_hip.h"
+
+namespace dewi {
+
+// Per-wave candidate lists hold at most kMaxListCandidates keys (4 register slots x 64 lanes);
+// larger candidate counts take the dense path (one key per row, selected afterwards).
+constexpr int kMaxListCandidates = 256;
+// The select / re-rank kernel sorts its candidates in LDS.
+constexpr int kMaxSortCandidates = 2048;
+constexpr int kScanThreads = 256;   // 4 waves per workgroup
+constexpr int kSelectThreads = 1024;
+
+struct ScanPlan {
+  int blocks;         // workgroups of kScanThreads
+  int waves;          // blocks * 4
+  int rows_per_iter;  // rows each wave loads before it reduces (fast path)
+  bool fast;          // dim == 256*U fp32 (U = 1..6), 16-byte aligned rows: row-per-wave kernel
+  bool dense;         // one key per row instead of per-wave lists
+  int group;          // generic path: lanes per row (power of two, <= 64)
+  int vec;            // generic path: 4 if rows can be read as float4, else 1
+  int nq_per_launch;  // queries handled by one corpus pass
+  int64_t keys_per_query;  // number of uint64 keys the scan emits per query
+  bool nontemporal;
+};
+
+struct Tuning {
+  int scan_blocks;
+  int rows_per_iter;
+  int nontemporal;  // -1 planner default, 0 off, 1 on
+};
+
+ScanPlan plan_scan(int64_t n_rows, int dim, int elem_bytes, int n_candidates, int compute_units,
+                   const Tuning& tuning);
+
+// ---- knn_scan.hip -------------------------------------------------------------------------
+// Normalises queries (cosine) into d_qn [n_queries][dim]; used by the generic scan path.
+hipError_t launch_prepare_queries(const float* d_q, float* d_qn, int n_queries, int dim, int space,
+                                  hipStream_t stream);
+// One corpus pass for queries [q0, q0+nq): emits plan.keys_per_query keys per query into
+// d_keys + q * plan.keys_per_query.
+hipError_t launch_scan_f32(const ScanPlan& plan, const float* d_E, int64_t n_rows, int dim, const float* d_q_raw,
+                           const float* d_q_norm, int q0, int nq, int n_candidates, int space, uint64_t* d_keys,
+                           hipStream_t stream);
+
+// ---- select_rerank.hip --------------------------------------------------------------------
+struct RerankParams {
+  float w_sim;   // fp32(1 - eta)
+  float w_dewi;  // fp32(eta)
+  float w_ent;   // fp32(entropy_pref)
+  int use_ent;   // entropy_pref != 0
+};
+// keys [n_queries][keys_per_query] -> top n_candidates by key -> either final (ids, scores) or
+// sorted candidate records.
+hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, int n_queries, int n_candidates,
+                                int k, const RerankParams& rp, const float* d_dewi32, const float* d_ent32,
+                                int64_t id_offset, int64_t* d_out_ids, float* d_out_scores,
+                                dewi_candidate* d_out_cand, hipStream_t stream);
+hipError_t launch_merge_rerank(const dewi_candidate* d_lists, int n_lists, int n_queries, int list_len,
+                               int n_candidates, int k, const RerankParams& rp, int64_t* d_out_ids,
+                               float* d_out_scores, hipStream_t stream);
+
+// ---- ingest.hip ---------------------------------------------------------------------------
+hipError_t launch_normalize_rows(const float* d_src, float* d_dst, int64_t n_rows, int dim, hipStream_t stream);
+hipError_t launch_f32_to_bf16(const float* d_src, uint16_t* d_dst, int64_t n, hipStream_t stream);
+hipError_t launch_payload_soa(const double* dewi, const double* ht, const double* hi, float* dewi32, float* ent32,
+                              int64_t n, hipStream_t stream);
+
+// ---- robust_stats.hip ---------------------------------------------------------------------
+size_t robust_fit_workspace_bytes(int n_signals);
+hipError_t launch_robust_fit(const float* d_S, int64_t n, int64_t ld, int n_signals, float* d_med, float* d_mad,
+                             void* d_ws, hipStream_t stream);
+struct ScoreParams {
+  double med[DEWI_NUM_SIGNALS];
+  double scale[DEWI_NUM_SIGNALS];  // 1.4826 * mad, the reference's denominator
+  double w[5];
+  double delta;
+  int mode;
+};
+hipError_t launch_score(const void* d_S, int is_f64, int64_t n, int64_t ld, const ScoreParams& sp, double* d_out,
+                        float* d_out32, hipStream_t stream);
+
+}  // namespace dewi

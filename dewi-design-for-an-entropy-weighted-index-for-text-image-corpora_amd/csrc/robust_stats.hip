@@ -1,0 +1,261 @@
+// Robust statistics (median / MAD) and the DEWI score for gfx950 (MI355X).
+//
+// Replaces scorer.RobustStats.fit (reference src/dewi/scorer.py:18-26) and
+// RobustStats.z + DewiScorer._components/score/score_conditional (:28-31, 49-89).
+//
+// fit: an exact order statistic needs no sort.  Each fp32 value is mapped to an order-preserving
+// 32-bit key and the two middle ranks are located by a 3-pass MSB-first radix select (11+11+10
+// bits): a pass histograms the keys that still match the decided prefix (LDS histogram per
+// workgroup, flushed to a global histogram with atomics), then a one-workgroup "pick" walks the
+// global histogram to the bin holding the rank.  Every pass streams the column once, so fit reads
+// 2 (median, MAD) x 3 x n_signals x n x 4 bytes — HBM/L2-bound and launch-latency dominated at
+// n = 1M.  Selection is order-independent, so the result is exactly NumPy's.
+//
+// score: one elementwise float64 kernel, 7 loads + 1 store per document, written so that every
+// intermediate rounds as in the reference (no FMA contraction: this file is built with
+// -ffp-contract=off and uses explicit __dmul_rn/__dadd_rn).
+#include "common.hpp"
+#include "launch.hpp"
+
+namespace dewi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBins = 2048;
+constexpr int kFitThreads = 256;
+
+struct FitState {       // per problem p = 2*signal + {0: lower middle, 1: upper middle}
+  uint32_t prefix;      // key bits decided so far (right-aligned)
+  uint32_t rank;        // 0-based ascending rank still to locate inside the prefix
+};
+
+struct FitWorkspace {
+  // laid out by robust_fit_workspace_bytes(); all arrays are per phase (0 median, 1 MAD)
+  uint32_t* hist;       // [2][3][P][kBins]
+  FitState* state;      // [2][P]
+  uint32_t* nan_count;  // [2][n_signals]
+};
+
+static FitWorkspace carve(void* ws, int n_signals) {
+  const int P = 2 * n_signals;
+  FitWorkspace w;
+  char* p = static_cast<char*>(ws);
+  w.hist = reinterpret_cast<uint32_t*>(p);
+  p += sizeof(uint32_t) * 2 * 3 * P * kBins;
+  w.state = reinterpret_cast<FitState*>(p);
+  p += sizeof(FitState) * 2 * P;
+  w.nan_count = reinterpret_cast<uint32_t*>(p);
+  return w;
+}
+
+size_t robust_fit_workspace_bytes(int n_signals) {
+  const size_t P = 2 * static_cast<size_t>(n_signals);
+  return sizeof(uint32_t) * 2 * 3 * P * kBins + sizeof(FitState) * 2 * P + sizeof(uint32_t) * 2 * n_signals + 256;
+}
+
+template <int PASS>
+__device__ __forceinline__ bool digit_of(uint32_t key, uint32_t prefix, uint32_t& digit) {
+  if constexpr (PASS == 0) {
+    digit = key >> 21;
+    return true;
+  } else if constexpr (PASS == 1) {
+    digit = (key >> 10) & 0x7FFu;
+    return (key >> 21) == prefix;
+  } else {
+    digit = key & 0x3FFu;
+    return (key >> 10) == prefix;
+  }
+}
+
+// grid (blocks_per_signal, n_signals).  MAD == true: keys are ord(|x - med[s]|), fp32 subtraction.
+template <int PASS, bool MAD>
+__global__ __launch_bounds__(kFitThreads) void fit_hist_kernel(const float* __restrict__ S, int64_t n, int64_t ld,
+                                                               const float* __restrict__ med,
+                                                               const FitState* __restrict__ state,
+                                                               uint32_t* __restrict__ hist,
+                                                               uint32_t* __restrict__ nan_count) {
+  __shared__ uint32_t lh[2][kBins];
+  __shared__ uint32_t lnan;
+  const int s = static_cast<int>(blockIdx.y);
+  const int tid = static_cast<int>(threadIdx.x);
+  for (int i = tid; i < 2 * kBins; i += kFitThreads) (&lh[0][0])[i] = 0;
+  if (tid == 0) lnan = 0;
+  __syncthreads();
+  const float* col = S + static_cast<int64_t>(s) * ld;
+  const float m = MAD ? med[s] : 0.f;
+  uint32_t pre0 = 0, pre1 = 0;
+  if constexpr (PASS > 0) {
+    pre0 = state[2 * s].prefix;
+    pre1 = state[2 * s + 1].prefix;
+  }
+  uint32_t nans = 0;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kFitThreads;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kFitThreads + tid; i < n; i += stride) {
+    float x = col[i];
+    if constexpr (MAD) x = __builtin_fabsf(__fsub_rn(x, m));
+    if constexpr (PASS == 0) nans += (x != x) ? 1u : 0u;
+    const uint32_t key = ord_f32(x);
+    uint32_t d;
+    if (digit_of<PASS>(key, pre0, d)) atomicAdd(&lh[0][d], 1u);
+    if (digit_of<PASS>(key, pre1, d)) atomicAdd(&lh[1][d], 1u);
+  }
+  if constexpr (PASS == 0) {
+    if (nans) atomicAdd(&lnan, nans);
+  }
+  __syncthreads();
+  uint32_t* gh = hist + static_cast<int64_t>(2 * s) * kBins;
+  for (int i = tid; i < 2 * kBins; i += kFitThreads) {
+    const uint32_t v = (&lh[0][0])[i];
+    if (v) atomicAdd(&gh[i], v);
+  }
+  if constexpr (PASS == 0) {
+    if (tid == 0 && lnan) atomicAdd(&nan_count[s], lnan);
+  }
+}
+
+// One workgroup per problem: find the bin holding `rank`, extend the prefix, rebase the rank.
+template <int PASS>
+__global__ __launch_bounds__(kFitThreads) void fit_pick_kernel(const uint32_t* __restrict__ hist,
+                                                               FitState* __restrict__ state, int64_t n) {
+  constexpr int BITS = PASS == 2 ? 10 : 11;
+  constexpr int PER = kBins / kFitThreads;  // 8 bins per thread
+  __shared__ uint32_t wave_tot[kFitThreads / kWave];
+  const int p = static_cast<int>(blockIdx.x);
+  const int tid = static_cast<int>(threadIdx.x), lane = tid & 63, wave = tid >> 6;
+  const uint32_t* h = hist + static_cast<int64_t>(p) * kBins;
+  uint32_t rank;
+  uint32_t prefix = 0;
+  if constexpr (PASS == 0) {
+    // lower middle (n-1)/2, upper middle n/2: identical when n is odd
+    rank = static_cast<uint32_t>((p & 1) ? (n / 2) : ((n - 1) / 2));
+  } else {
+    rank = state[p].rank;
+    prefix = state[p].prefix;
+  }
+  uint32_t v[PER], local = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    v[j] = h[tid * PER + j];
+    local += v[j];
+  }
+  uint32_t incl = local;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = __shfl_up(incl, off, kWave);
+    if (lane >= off) incl += o;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t before = incl - local;
+  for (int w = 0; w < wave; ++w) before += wave_tot[w];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    if (rank >= before && rank < before + v[j]) {
+      FitState st;
+      st.prefix = (prefix << BITS) | static_cast<uint32_t>(tid * PER + j);
+      st.rank = rank - before;
+      state[p] = st;
+    }
+    before += v[j];
+  }
+}
+
+// med[s] / mad[s] from the two located keys.  NumPy: even n -> mean of the two middles computed in
+// fp32 ((a+b)/2); any NaN in the column -> NaN.
+__global__ void fit_finish_kernel(const FitState* __restrict__ state, const uint32_t* __restrict__ nan_count,
+                                  int n_signals, int64_t n, float* __restrict__ out) {
+  const int s = static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x);
+  if (s >= n_signals) return;
+  const float a = unord_f32(state[2 * s].prefix);
+  const float b = unord_f32(state[2 * s + 1].prefix);
+  float r = __fmul_rn(__fadd_rn(a, b), 0.5f);
+  if (n & 1) r = a;
+  if (nan_count[s]) r = __builtin_nanf("");
+  out[s] = r;
+}
+
+template <bool MAD>
+static void run_phase(const float* S, int64_t n, int64_t ld, int n_signals, const float* med, FitWorkspace w,
+                      float* out, hipStream_t stream) {
+  const int phase = MAD ? 1 : 0;
+  const int P = 2 * n_signals;
+  uint32_t* hist = w.hist + static_cast<int64_t>(phase) * 3 * P * kBins;
+  FitState* state = w.state + phase * P;
+  uint32_t* nanc = w.nan_count + phase * n_signals;
+  int64_t bx = (n + kFitThreads * 16 - 1) / (kFitThreads * 16);
+  if (bx < 1) bx = 1;
+  if (bx > 512) bx = 512;
+  const dim3 grid(static_cast<unsigned>(bx), static_cast<unsigned>(n_signals));
+  uint32_t* h0 = hist;
+  uint32_t* h1 = hist + static_cast<int64_t>(P) * kBins;
+  uint32_t* h2 = hist + static_cast<int64_t>(2) * P * kBins;
+  hipLaunchKernelGGL((fit_hist_kernel<0, MAD>), grid, dim3(kFitThreads), 0, stream, S, n, ld, med, state, h0, nanc);
+  hipLaunchKernelGGL((fit_pick_kernel<0>), dim3(P), dim3(kFitThreads), 0, stream, h0, state, n);
+  hipLaunchKernelGGL((fit_hist_kernel<1, MAD>), grid, dim3(kFitThreads), 0, stream, S, n, ld, med, state, h1, nanc);
+  hipLaunchKernelGGL((fit_pick_kernel<1>), dim3(P), dim3(kFitThreads), 0, stream, h1, state, n);
+  hipLaunchKernelGGL((fit_hist_kernel<2, MAD>), grid, dim3(kFitThreads), 0, stream, S, n, ld, med, state, h2, nanc);
+  hipLaunchKernelGGL((fit_pick_kernel<2>), dim3(P), dim3(kFitThreads), 0, stream, h2, state, n);
+  hipLaunchKernelGGL(fit_finish_kernel, dim3((n_signals + 63) / 64), dim3(64), 0, stream, state, nanc, n_signals, n, out);
+}
+
+hipError_t launch_robust_fit(const float* d_S, int64_t n, int64_t ld, int n_signals, float* d_med, float* d_mad,
+                             void* d_ws, hipStream_t stream) {
+  FitWorkspace w = carve(d_ws, n_signals);
+  hipError_t e = hipMemsetAsync(d_ws, 0, robust_fit_workspace_bytes(n_signals), stream);
+  if (e != hipSuccess) return e;
+  run_phase<false>(d_S, n, ld, n_signals, nullptr, w, d_med, stream);
+  run_phase<true>(d_S, n, ld, n_signals, d_med, w, d_mad, stream);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// score
+// ---------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void score_kernel(const T* __restrict__ S, int64_t n, int64_t ld, ScoreParams sp,
+                                                    double* __restrict__ out, float* __restrict__ out32) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    double z[DEWI_NUM_SIGNALS];
+#pragma unroll
+    for (int s = 0; s < DEWI_NUM_SIGNALS; ++s) {
+      const double x = static_cast<double>(S[static_cast<int64_t>(s) * ld + i]);
+      z[s] = __ddiv_rn(__dsub_rn(x, sp.med[s]), sp.scale[s]);            // scorer.py:28-31
+    }
+    const double Ht = __dmul_rn(0.5, __dadd_rn(z[0], z[1]));               // scorer.py:53
+    const double Hi = __dmul_rn(0.5, __dadd_rn(z[2], z[3]));               // scorer.py:54
+    const double I = z[4], R = z[5], Nz = z[6];
+    double U;
+    if (sp.mode == DEWI_MODE_STANDARD) {                                   // scorer.py:67-73
+      U = __dadd_rn(__dmul_rn(sp.w[0], Ht), __dmul_rn(sp.w[1], Hi));
+      U = __dsub_rn(U, __dmul_rn(sp.w[2], I));
+    } else {                                                               // scorer.py:80-87
+      U = __dadd_rn(__dmul_rn(sp.w[0], __dsub_rn(Ht, I)), __dmul_rn(sp.w[1], __dsub_rn(Hi, I)));
+    }
+    U = __dsub_rn(U, __dmul_rn(sp.w[3], R));
+    U = __dsub_rn(U, __dmul_rn(sp.w[4], Nz));
+    // np.clip(U, -delta, delta): minimum(maximum(U, lo), hi); NaN propagates
+    if (U == U) {
+      U = U < -sp.delta ? -sp.delta : U;
+      U = U > sp.delta ? sp.delta : U;
+    }
+    const double r = __ddiv_rn(1.0, __dadd_rn(1.0, exp(-U)));              // scorer.py:60-62
+    out[i] = r;
+    if (out32) out32[i] = static_cast<float>(r);
+  }
+}
+
+hipError_t launch_score(const void* d_S, int is_f64, int64_t n, int64_t ld, const ScoreParams& sp, double* d_out,
+                        float* d_out32, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (is_f64)
+    hipLaunchKernelGGL(score_kernel<double>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream,
+                       static_cast<const double*>(d_S), n, ld, sp, d_out, d_out32);
+  else
+    hipLaunchKernelGGL(score_kernel<float>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream,
+                       static_cast<const float*>(d_S), n, ld, sp, d_out, d_out32);
+  return hipGetLastError();
+}
+
+}  // namespace dewi

@@ -1,0 +1,268 @@
+// Candidate selection, DEWI blend and final top-k for gfx950 (MI355X).
+//
+// Replaces steps 3-9 of ExactIndex.search (reference src/dewi/backends.py:439-481):
+//   top = argpartition(scores, -c)[-c:]                    -> block radix-select over the scan's keys
+//   adj = (1-eta)*scores[top] + eta*dewi[top] (+pref*ent)  -> fp32, two rounded products + one add
+//   argpartition(adj, -k)[-k:], argsort(-adj)              -> bitonic sort in LDS, first k
+// One workgroup per query.  The work is O(keys) with keys << corpus bytes; this kernel is
+// latency-bound, not bandwidth-bound, and is kept to a handful of passes over L2-resident keys.
+#include "common.hpp"
+#include "launch.hpp"
+
+namespace dewi {
+
+struct SelectShared {
+  uint64_t sel[kMaxSortCandidates];   // selected candidate keys, then sorted descending
+  uint64_t sel2[kMaxSortCandidates];  // re-rank keys
+  uint32_t val[kMaxSortCandidates];   // payload carried through the first sort (merge path)
+  uint32_t hist[256];
+  uint32_t wave_tot[4];
+  uint32_t pick_digit, pick_above, pick_count, total;
+  uint32_t count;
+};
+
+// Descending bitonic sort of p2 (power of two) keys in LDS, optional 32-bit payload.
+template <bool WITH_VAL>
+__device__ void bitonic_sort_desc(uint64_t* key, uint32_t* val, int p2) {
+  const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
+  for (int size = 2; size <= p2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int t = tid; t < (p2 >> 1); t += nt) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool first_half = (lo & size) == 0;
+        const uint64_t a = key[lo], b = key[hi];
+        if (first_half ? (a < b) : (a > b)) {
+          key[lo] = b;
+          key[hi] = a;
+          if constexpr (WITH_VAL) {
+            const uint32_t va = val[lo];
+            val[lo] = val[hi];
+            val[hi] = va;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// Threshold T such that exactly `kth` of the non-empty keys are >= T (keys are unique).  If fewer
+// than `kth` non-empty keys exist, returns 1 (every non-empty key).  All threads return the same
+// value.  MSB-first radix select, 8 bits per pass, early exit once a whole bin is taken.
+__device__ uint64_t block_kth_largest(const uint64_t* __restrict__ keys, int64_t m, uint32_t kth, SelectShared& sh) {
+  const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
+  const int lane = tid & 63, wave = tid >> 6;
+  uint64_t prefix = 0;
+  uint32_t remaining = kth;
+  for (int shift = 56; shift >= 0; shift -= 8) {
+    if (tid < 256) sh.hist[tid] = 0;
+    __syncthreads();
+    for (int64_t i = tid; i < m; i += nt) {
+      const uint64_t k = keys[i];
+      if (k != kKeyEmpty && (shift == 56 || (k >> (shift + 8)) == prefix))
+        atomicAdd(&sh.hist[static_cast<uint32_t>(k >> shift) & 0xFFu], 1u);
+    }
+    __syncthreads();
+    uint32_t h = 0, sfx = 0;
+    if (tid < 256) {  // waves 0..3, all lanes active
+      h = sh.hist[tid];
+      sfx = h;
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_down(sfx, off, kWave);
+        if (lane + off < 64) sfx += o;
+      }
+      if (lane == 0) sh.wave_tot[wave] = sfx;
+    }
+    __syncthreads();
+    if (tid < 256) {
+      uint32_t above = 0;
+      for (int w = wave + 1; w < 4; ++w) above += sh.wave_tot[w];
+      const uint32_t incl = sfx + above;  // keys (under this prefix) with digit >= tid
+      const uint32_t excl = incl - h;     // ... with digit > tid
+      if (tid == 0) sh.total = incl;
+      if (incl >= remaining && excl < remaining) {
+        sh.pick_digit = static_cast<uint32_t>(tid);
+        sh.pick_above = excl;
+        sh.pick_count = h;
+      }
+    }
+    __syncthreads();
+    if (sh.total < remaining) return 1ull;  // only possible on the first pass: fewer keys than kth
+    prefix = (prefix << 8) | sh.pick_digit;
+    remaining -= sh.pick_above;
+    const bool whole_bin = sh.pick_count == remaining;
+    __syncthreads();  // pick_* are rewritten by the next pass
+    if (whole_bin) return prefix << shift;
+  }
+  return prefix;
+}
+
+__device__ __forceinline__ float blend(const RerankParams& rp, float sim, float dewi, float ent) {
+  // reference backends.py:461-465: (1-eta)*s and eta*dewi are rounded separately, then added.
+  float adj = __fadd_rn(__fmul_rn(rp.w_sim, sim), __fmul_rn(rp.w_dewi, dewi));
+  if (rp.use_ent) adj = __fadd_rn(adj, __fmul_rn(rp.w_ent, ent));
+  return adj;
+}
+
+__device__ __forceinline__ int pow2_at_least(int v) {
+  int p = 2;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+// After sh.sel[0..n_sel) holds the candidates sorted by (sim desc, row asc) and dewi/ent of entry t
+// are available through `fetch(t, &dewi, &ent, &id)`: blend, sort, emit the first k.
+template <class Fetch>
+__device__ void rerank_and_emit(SelectShared& sh, int n_sel, int k, const RerankParams& rp, Fetch fetch,
+                                int64_t* __restrict__ out_ids, float* __restrict__ out_scores) {
+  const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
+  const int p2 = pow2_at_least(n_sel);
+  for (int t = tid; t < p2; t += nt) {
+    uint64_t k2 = kKeyEmpty;
+    if (t < n_sel) {
+      float dewi, ent;
+      int64_t id;
+      fetch(t, dewi, ent, id);
+      const float adj = blend(rp, key_score(sh.sel[t]), dewi, ent);
+      // ties on the adjusted score: the candidate that ranked higher on similarity first
+      k2 = (static_cast<uint64_t>(ord_f32(adj)) << 32) | static_cast<uint64_t>(0xFFFFFFFFu - static_cast<uint32_t>(t));
+    }
+    sh.sel2[t] = k2;
+  }
+  bitonic_sort_desc<false>(sh.sel2, nullptr, p2);
+  for (int j = tid; j < k && j < n_sel; j += nt) {
+    const uint64_t k2 = sh.sel2[j];
+    const int t = static_cast<int>(0xFFFFFFFFu - static_cast<uint32_t>(k2));
+    float dewi, ent;
+    int64_t id;
+    fetch(t, dewi, ent, id);
+    out_ids[j] = id;
+    out_scores[j] = unord_f32(static_cast<uint32_t>(k2 >> 32));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Single-device (or per-shard) select: keys from the scan -> final results or candidate records.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(
+    const uint64_t* __restrict__ keys_all, int64_t keys_per_query, int n_candidates, int k, RerankParams rp,
+    const float* __restrict__ dewi32, const float* __restrict__ ent32, int64_t id_offset,
+    int64_t* __restrict__ out_ids, float* __restrict__ out_scores, dewi_candidate* __restrict__ out_cand) {
+  __shared__ SelectShared sh;
+  const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
+  const int q = static_cast<int>(blockIdx.x);
+  const uint64_t* keys = keys_all + static_cast<int64_t>(q) * keys_per_query;
+
+  const uint64_t thr = block_kth_largest(keys, keys_per_query, static_cast<uint32_t>(n_candidates), sh);
+  if (tid == 0) sh.count = 0;
+  const int p2 = pow2_at_least(n_candidates);
+  for (int t = tid; t < p2; t += nt) sh.sel[t] = kKeyEmpty;
+  __syncthreads();
+  for (int64_t i = tid; i < keys_per_query; i += nt) {
+    const uint64_t key = keys[i];
+    if (key != kKeyEmpty && key >= thr) {
+      const uint32_t pos = atomicAdd(&sh.count, 1u);
+      if (pos < static_cast<uint32_t>(p2)) sh.sel[pos] = key;
+    }
+  }
+  __syncthreads();
+  const int n_sel = static_cast<int>(sh.count < static_cast<uint32_t>(n_candidates) ? sh.count : n_candidates);
+  bitonic_sort_desc<false>(sh.sel, nullptr, p2);
+
+  if (out_cand != nullptr) {
+    dewi_candidate* oc = out_cand + static_cast<int64_t>(q) * n_candidates;
+    for (int t = tid; t < n_candidates; t += nt) {
+      dewi_candidate rec;
+      if (t < n_sel) {
+        const uint32_t row = key_row(sh.sel[t]);
+        rec.sim = key_score(sh.sel[t]);
+        rec.dewi = dewi32[row];
+        rec.ent = ent32[row];
+        rec.id = static_cast<int32_t>(static_cast<int64_t>(row) + id_offset);
+      } else {
+        rec.sim = -__builtin_inff();
+        rec.dewi = 0.f;
+        rec.ent = 0.f;
+        rec.id = -1;
+      }
+      oc[t] = rec;
+    }
+    return;
+  }
+  auto fetch = [&](int t, float& dewi, float& ent, int64_t& id) {
+    const uint32_t row = key_row(sh.sel[t]);
+    dewi = dewi32[row];
+    ent = ent32[row];
+    id = static_cast<int64_t>(row) + id_offset;
+  };
+  rerank_and_emit(sh, n_sel, k, rp, fetch, out_ids + static_cast<int64_t>(q) * k,
+                  out_scores + static_cast<int64_t>(q) * k);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-shard merge: n_lists sorted candidate lists per query -> global top-c -> blend -> top-k.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kSelectThreads) void merge_rerank_kernel(const dewi_candidate* __restrict__ lists,
+                                                                      int n_lists, int n_queries, int list_len,
+                                                                      int n_candidates, int k, RerankParams rp,
+                                                                      int64_t* __restrict__ out_ids,
+                                                                      float* __restrict__ out_scores) {
+  __shared__ SelectShared sh;
+  const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
+  const int q = static_cast<int>(blockIdx.x);
+  const int m = n_lists * list_len;
+  const int p2 = pow2_at_least(m);
+  if (tid == 0) sh.count = 0;
+  __syncthreads();
+  for (int t = tid; t < p2; t += nt) {
+    uint64_t key = kKeyEmpty;
+    uint32_t src = 0;
+    if (t < m) {
+      const int l = t / list_len, j = t % list_len;
+      const int64_t at = (static_cast<int64_t>(l) * n_queries + q) * list_len + j;
+      const dewi_candidate rec = lists[at];
+      if (rec.id >= 0) {
+        key = make_key(rec.sim, static_cast<uint32_t>(rec.id));
+        src = static_cast<uint32_t>(t);
+        atomicAdd(&sh.count, 1u);
+      }
+    }
+    sh.sel[t] = key;
+    sh.val[t] = src;
+  }
+  bitonic_sort_desc<true>(sh.sel, sh.val, p2);
+  const int n_sel = static_cast<int>(sh.count < static_cast<uint32_t>(n_candidates) ? sh.count : n_candidates);
+  auto fetch = [&](int t, float& dewi, float& ent, int64_t& id) {
+    const int s = static_cast<int>(sh.val[t]);
+    const int l = s / list_len, j = s % list_len;
+    const dewi_candidate rec = lists[(static_cast<int64_t>(l) * n_queries + q) * list_len + j];
+    dewi = rec.dewi;
+    ent = rec.ent;
+    id = rec.id;
+  };
+  rerank_and_emit(sh, n_sel, k, rp, fetch, out_ids + static_cast<int64_t>(q) * k,
+                  out_scores + static_cast<int64_t>(q) * k);
+}
+
+hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, int n_queries, int n_candidates,
+                                int k, const RerankParams& rp, const float* d_dewi32, const float* d_ent32,
+                                int64_t id_offset, int64_t* d_out_ids, float* d_out_scores,
+                                dewi_candidate* d_out_cand, hipStream_t stream) {
+  const int threads = keys_per_query <= 4096 && n_candidates <= 128 ? 256 : kSelectThreads;
+  hipLaunchKernelGGL(select_rerank_kernel, dim3(n_queries), dim3(threads), 0, stream, d_keys, keys_per_query,
+                     n_candidates, k, rp, d_dewi32, d_ent32, id_offset, d_out_ids, d_out_scores, d_out_cand);
+  return hipGetLastError();
+}
+
+hipError_t launch_merge_rerank(const dewi_candidate* d_lists, int n_lists, int n_queries, int list_len,
+                               int n_candidates, int k, const RerankParams& rp, int64_t* d_out_ids,
+                               float* d_out_scores, hipStream_t stream) {
+  const int threads = n_lists * list_len <= 512 ? 256 : kSelectThreads;
+  hipLaunchKernelGGL(merge_rerank_kernel, dim3(n_queries), dim3(threads), 0, stream, d_lists, n_lists, n_queries,
+                     list_len, n_candidates, k, rp, d_out_ids, d_out_scores);
+  return hipGetLastError();
+}
+
+}  // namespace dewi

@@ -1,0 +1,235 @@
+"""Device-resident corpus + thin wrappers over the C ABI.
+
+``DeviceCorpus`` owns what the search path needs in HBM — the N x d embedding matrix
+(row-major, already normalised for cosine) and the two fp32 payload columns the re-rank
+reads — and turns a query batch into (row ids, adjusted scores) with exactly two kernel
+launches (scan, select/re-rank).  PyTorch is used only for device memory, streams and
+host<->device copies.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional, Tuple, Union
+
+import numpy as np
+
+from . import _native as nat
+
+ArrayLike = Union[np.ndarray, "torch.Tensor"]  # noqa: F821
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class DeviceCorpus:
+    """Embedding block + payload columns of one doc-id shard, resident on one GPU."""
+
+    def __init__(self, emb, dewi32, ent32, space: str = "cosine", id_offset: int = 0):
+        torch = _torch()
+        if space not in nat.SPACE_CODES:
+            raise ValueError(f"unknown space {space!r}")
+        assert emb.is_cuda and emb.dim() == 2 and emb.is_contiguous()
+        assert emb.dtype in (torch.float32, torch.bfloat16)
+        self.emb = emb
+        self.dewi32 = dewi32.contiguous()
+        self.ent32 = ent32.contiguous()
+        assert self.dewi32.dtype == torch.float32 and self.ent32.dtype == torch.float32
+        assert self.dewi32.numel() == emb.shape[0] == self.ent32.numel()
+        self.space = space
+        self.id_offset = int(id_offset)
+        self.device = emb.device
+        self._lib = nat.load_library()
+        self._ws: Dict[Tuple[int, int], "torch.Tensor"] = {}
+        self._q_pinned = None
+        self._q_dev = None
+
+    # ------------------------------------------------------------------ construction
+    @classmethod
+    def from_host(cls, rows: np.ndarray, dewi: np.ndarray, ht_mean: np.ndarray, hi_mean: np.ndarray,
+                  space: str = "cosine", normalize: Optional[bool] = None, device: Optional[str] = None,
+                  id_offset: int = 0, chunk_rows: int = 262144) -> "DeviceCorpus":
+        """Upload raw fp32 rows and payload columns; normalise on the device (A1/A2).
+
+        Replaces N x ``ExactIndex.add`` + ``build`` (reference backends.py:394-412).  Rows
+        are streamed in chunks so that the host never needs a second copy of the matrix.
+        """
+        torch = _torch()
+        lib = nat.load_library()
+        dev = torch.device(device or f"cuda:{torch.cuda.current_device()}")
+        rows = np.asarray(rows)
+        if rows.ndim != 2 or rows.shape[0] == 0:
+            raise ValueError("No embeddings to build index from")
+        n, d = rows.shape
+        if normalize is None:
+            normalize = space == "cosine"
+        emb = torch.empty((n, d), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            for s in range(0, n, chunk_rows):
+                e = min(n, s + chunk_rows)
+                blk = torch.from_numpy(np.ascontiguousarray(rows[s:e], dtype=np.float32))
+                emb[s:e].copy_(blk, non_blocking=False)
+            if normalize:
+                nat.check(lib.dewi_normalize_rows_f32(nat.ptr(emb), nat.ptr(emb), n, d, nat.stream_ptr()))
+            cols = [torch.from_numpy(np.ascontiguousarray(c, dtype=np.float64)).to(dev) for c in (dewi, ht_mean, hi_mean)]
+            if any(c.numel() != n for c in cols):
+                raise ValueError("payload columns must have one value per row")
+            dewi32 = torch.empty(n, dtype=torch.float32, device=dev)
+            ent32 = torch.empty(n, dtype=torch.float32, device=dev)
+            nat.check(lib.dewi_payload_soa_f64(nat.ptr(cols[0]), nat.ptr(cols[1]), nat.ptr(cols[2]), nat.ptr(dewi32),
+                                               nat.ptr(ent32), n, nat.stream_ptr()))
+            torch.cuda.current_stream().synchronize()
+        return cls(emb, dewi32, ent32, space, id_offset)
+
+    def to_bf16(self) -> "DeviceCorpus":
+        """The same shard with the (already normalised) matrix rounded to bf16 (config C3)."""
+        torch = _torch()
+        out = torch.empty(self.emb.shape, dtype=torch.bfloat16, device=self.device)
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.dewi_convert_f32_to_bf16(nat.ptr(self.emb), nat.ptr(out), self.emb.numel(),
+                                                         nat.stream_ptr()))
+        return DeviceCorpus(out, self.dewi32, self.ent32, self.space, self.id_offset)
+
+    # ------------------------------------------------------------------ properties
+    @property
+    def n_rows(self) -> int:
+        return int(self.emb.shape[0])
+
+    @property
+    def dim(self) -> int:
+        return int(self.emb.shape[1])
+
+    @property
+    def is_bf16(self) -> bool:
+        return self.emb.dtype == _torch().bfloat16
+
+    def corpus_bytes(self) -> int:
+        return self.emb.numel() * self.emb.element_size()
+
+    # ------------------------------------------------------------------ helpers
+    def _workspace(self, n_queries: int, n_candidates: int):
+        # the required size depends on the launch plan (tunable), so it is re-asked every call
+        need = int(self._lib.dewi_knn_workspace_bytes(self.n_rows, self.dim, n_queries, n_candidates))
+        if need == 0:
+            raise nat.NativeLibraryError("dewi_knn_workspace_bytes returned 0: " + nat.last_error())
+        key = (n_queries, n_candidates)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            if len(self._ws) > 8:
+                self._ws.clear()
+            ws = _torch().empty(need, dtype=_torch().uint8, device=self.device)
+            self._ws[key] = ws
+        return ws
+
+    def stage_queries(self, queries: ArrayLike):
+        """Host or device query batch -> contiguous fp32 [B, d] tensor on this device."""
+        torch = _torch()
+        if isinstance(queries, torch.Tensor):
+            q = queries
+            if q.dim() == 1:
+                q = q.unsqueeze(0)
+            return q.to(device=self.device, dtype=torch.float32).contiguous()
+        q = np.asarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q.reshape(1, -1)
+        q = np.ascontiguousarray(q)
+        if self._q_pinned is None or self._q_pinned.shape != q.shape:
+            self._q_pinned = torch.empty(q.shape, dtype=torch.float32, pin_memory=True)
+            self._q_dev = torch.empty(q.shape, dtype=torch.float32, device=self.device)
+        self._q_pinned.numpy()[...] = q
+        self._q_dev.copy_(self._q_pinned, non_blocking=True)
+        return self._q_dev
+
+    # ------------------------------------------------------------------ hot path
+    def search_device(self, q_dev, k: int, eta: float, entropy_pref: float, out_ids=None, out_scores=None):
+        """Enqueue one search on the current stream; returns device tensors, no sync.
+
+        q_dev: fp32 [B, d] on this device (raw queries; cosine normalisation happens in-kernel).
+        """
+        torch = _torch()
+        b = int(q_dev.shape[0])
+        if q_dev.shape[1] != self.dim:
+            raise ValueError(f"Expected query shape ({self.dim},), got {tuple(q_dev.shape[1:])}")
+        k = int(k)
+        if k <= 0:
+            return (torch.empty((b, 0), dtype=torch.int64, device=self.device),
+                    torch.empty((b, 0), dtype=torch.float32, device=self.device))
+        c = min(2 * k, self.n_rows)
+        if out_ids is None:
+            out_ids = torch.empty((b, k), dtype=torch.int64, device=self.device)
+        if out_scores is None:
+            out_scores = torch.empty((b, k), dtype=torch.float32, device=self.device)
+        ws = self._workspace(b, max(c, 1))
+        fn = self._lib.dewi_knn_rerank_bf16 if self.is_bf16 else self._lib.dewi_knn_rerank_f32
+        rc = fn(nat.ptr(self.emb), self.n_rows, self.dim, nat.ptr(q_dev), b, nat.ptr(self.dewi32), nat.ptr(self.ent32),
+                k, float(eta), float(entropy_pref), nat.SPACE_CODES[self.space], nat.ptr(out_ids), nat.ptr(out_scores),
+                nat.ptr(ws), ws.numel(), nat.stream_ptr())
+        nat.check(rc)
+        return out_ids, out_scores
+
+    def search(self, queries: ArrayLike, k: int = 10, eta: float = 0.5, entropy_pref: float = 0.0
+               ) -> Tuple[np.ndarray, np.ndarray]:
+        """Blocking convenience: (ids int64 [B,k] including id_offset, scores fp32 [B,k]) on the host."""
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            q = self.stage_queries(queries)
+            ids, scores = self.search_device(q, k, eta, entropy_pref)
+            ids_h = ids.cpu().numpy()
+            scores_h = scores.cpu().numpy()
+        if self.id_offset:
+            ids_h = ids_h + self.id_offset
+        return ids_h, scores_h
+
+    def candidates_device(self, q_dev, n_candidates: int, out=None):
+        """Per-shard top-``n_candidates`` records, int32 view [B, n_candidates, 4] (16 B each)."""
+        torch = _torch()
+        b = int(q_dev.shape[0])
+        if out is None:
+            out = torch.empty((b, n_candidates, 4), dtype=torch.int32, device=self.device)
+        c_local = max(1, min(n_candidates, self.n_rows))
+        ws = self._workspace(b, c_local)
+        rc = self._lib.dewi_knn_candidates(nat.ptr(self.emb), 1 if self.is_bf16 else 0, self.n_rows, self.dim,
+                                           nat.ptr(q_dev), b, nat.ptr(self.dewi32), nat.ptr(self.ent32),
+                                           int(n_candidates), nat.SPACE_CODES[self.space], self.id_offset, nat.ptr(out),
+                                           nat.ptr(ws), ws.numel(), nat.stream_ptr())
+        nat.check(rc)
+        return out
+
+
+def merge_rerank_device(lists, n_candidates: int, k: int, eta: float, entropy_pref: float, out_ids=None,
+                        out_scores=None):
+    """lists: int32 [n_lists, B, list_len, 4] candidate records (the all-gather result)."""
+    torch = _torch()
+    lib = nat.load_library()
+    n_lists, b, list_len = int(lists.shape[0]), int(lists.shape[1]), int(lists.shape[2])
+    if out_ids is None:
+        out_ids = torch.empty((b, k), dtype=torch.int64, device=lists.device)
+    if out_scores is None:
+        out_scores = torch.empty((b, k), dtype=torch.float32, device=lists.device)
+    rc = lib.dewi_merge_rerank(nat.ptr(lists), n_lists, b, list_len, int(n_candidates), int(k), float(eta),
+                               float(entropy_pref), nat.ptr(out_ids), nat.ptr(out_scores), nat.stream_ptr())
+    nat.check(rc)
+    return out_ids, out_scores
+
+
+def records_to_numpy(recs) -> np.ndarray:
+    """int32 [.., 4] record tensor -> structured host array (sim, dewi, ent, id)."""
+    a = recs.detach().cpu().numpy()
+    dt = np.dtype([("sim", np.float32), ("dewi", np.float32), ("ent", np.float32), ("id", np.int32)])
+    return np.ascontiguousarray(a).view(dt).reshape(a.shape[:-1])
+
+
+def timing(enable: bool) -> None:
+    nat.check(nat.load_library().dewi_timing_enable(1 if enable else 0))
+
+
+def timing_read() -> Tuple[float, int]:
+    ms = ctypes.c_double(0.0)
+    n = ctypes.c_int(0)
+    nat.check(nat.load_library().dewi_timing_read(ctypes.byref(ms), ctypes.byref(n)))
+    return float(ms.value), int(n.value)
+
+
+def tuning(scan_blocks: int = 0, rows_per_iter: int = 0, nontemporal: int = -1) -> None:
+    nat.check(nat.load_library().dewi_tuning_set(int(scan_blocks), int(rows_per_iter), int(nontemporal)))

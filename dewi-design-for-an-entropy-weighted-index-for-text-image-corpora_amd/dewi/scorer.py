@@ -1,0 +1,127 @@
+"""Robust DEWI scorer on the GPU (reference ``src/dewi/scorer.py``).
+
+``RobustStats.fit`` runs the exact-median radix select of ``csrc/robust_stats.hip``;
+``DewiScorer.score`` / ``score_conditional`` (one document) and ``score_batch`` (columns)
+run the float64 score kernel.  Semantics kept from the reference, including its quirks:
+
+* ``fit`` sees every value rounded to fp32 (scorer.py:21) while scoring uses the caller's
+  float64 value (scorer.py:28-31);
+* an exactly-zero MAD becomes 1e-8 (scorer.py:24);
+* the constructor always overwrites ``weights.delta`` with its ``delta`` argument and
+  mutates the caller's ``Weights`` object (scorer.py:37-40).
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Dict, List, Mapping, Optional, Sequence
+
+import numpy as np
+
+from . import _native as nat
+from .types import SIGNAL_FIELDS, Weights
+
+
+def _fit_columns(columns: Mapping[str, np.ndarray]) -> (Dict[str, float], Dict[str, float]):
+    """fp32 columns -> (medians, MADs) through ``dewi_robust_fit_f32``."""
+    import torch
+    lib = nat.load_library()
+    keys = list(columns.keys())
+    n = len(columns[keys[0]])
+    if n == 0:
+        raise IndexError("cannot fit robust statistics on an empty table")
+    host = np.empty((len(keys), n), dtype=np.float32)
+    for j, key in enumerate(keys):
+        host[j] = np.asarray(columns[key], dtype=np.float32)          # scorer.py:21 — fp32 cast
+    dev = torch.from_numpy(host).cuda()
+    med = torch.empty(len(keys), dtype=torch.float32, device=dev.device)
+    mad = torch.empty(len(keys), dtype=torch.float32, device=dev.device)
+    ws_bytes = int(lib.dewi_robust_fit_workspace_bytes(len(keys)))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev.device)
+    nat.check(lib.dewi_robust_fit_f32(nat.ptr(dev), n, n, len(keys), nat.ptr(med), nat.ptr(mad), nat.ptr(ws), ws_bytes,
+                                      nat.stream_ptr()))
+    med_h = med.cpu().numpy().astype(np.float64)
+    mad_h = mad.cpu().numpy().astype(np.float64)
+    medians = {k: float(med_h[j]) for j, k in enumerate(keys)}
+    mads = {k: float(mad_h[j]) or 1e-8 for j, k in enumerate(keys)}    # scorer.py:24
+    return medians, mads
+
+
+@dataclass
+class RobustStats:
+    """Median and MAD per signal (reference scorer.py:11-31)."""
+
+    medians: Dict[str, float]
+    mads: Dict[str, float]
+
+    @classmethod
+    def fit(cls, rows: List[Dict[str, float]]) -> "RobustStats":
+        keys = list(rows[0].keys())
+        cols = {k: np.fromiter((r[k] for r in rows), dtype=np.float64, count=len(rows)) for k in keys}
+        return cls(*_fit_columns(cols))
+
+    @classmethod
+    def fit_columns(cls, columns: Mapping[str, np.ndarray]) -> "RobustStats":
+        """Bulk form of ``fit``: one array per signal instead of one dict per document."""
+        return cls(*_fit_columns(columns))
+
+    def z(self, name: str, val: float) -> float:
+        return float((val - self.medians[name]) / (1.4826 * self.mads[name]))
+
+
+class DewiScorer:
+    """Standard and conditional DEWI score (reference scorer.py:34-89)."""
+
+    def __init__(self, weights: Optional[Weights] = None, delta: float = 3.0):
+        self.weights = weights or Weights()
+        self.weights.delta = delta
+        self.stats: Optional[RobustStats] = None
+
+    # -- fitting ---------------------------------------------------------------------
+    def fit_stats(self, rows: List[Dict[str, float]]) -> None:
+        self.stats = RobustStats.fit(rows)
+
+    def fit_stats_columns(self, columns: Mapping[str, np.ndarray]) -> None:
+        self.stats = RobustStats.fit_columns(columns)
+
+    def is_fitted(self) -> bool:
+        return self.stats is not None
+
+    # -- scoring ---------------------------------------------------------------------
+    def _run(self, columns: Mapping[str, Sequence[float]], mode: str, want32: bool = False):
+        import torch
+        assert self.stats is not None, "Call fit_stats() before scoring."
+        lib = nat.load_library()
+        cols = [np.atleast_1d(np.asarray(columns[k])) for k in SIGNAL_FIELDS]      # KeyError on a missing signal
+        n = cols[0].shape[0]
+        as_f64 = any(c.dtype != np.float32 for c in cols)
+        host = np.empty((len(SIGNAL_FIELDS), n), dtype=np.float64 if as_f64 else np.float32)
+        for j, c in enumerate(cols):
+            host[j] = c
+        dev = torch.from_numpy(host).cuda()
+        out = torch.empty(n, dtype=torch.float64, device=dev.device)
+        out32 = torch.empty(n, dtype=torch.float32, device=dev.device) if want32 else None
+        arr = ctypes.c_double * len(SIGNAL_FIELDS)
+        med = arr(*[self.stats.medians[k] for k in SIGNAL_FIELDS])
+        mad = arr(*[self.stats.mads[k] for k in SIGNAL_FIELDS])
+        w = (ctypes.c_double * 5)(*self.weights.as_vector().tolist())
+        nat.check(lib.dewi_score_f64(nat.ptr(dev), 1 if as_f64 else 0, n, n, med, mad, w, float(self.weights.delta),
+                                     nat.MODE_CODES[mode], nat.ptr(out), nat.ptr(out32), nat.stream_ptr()))
+        res = out.cpu().numpy()
+        return (res, out32.cpu().numpy()) if want32 else res
+
+    def score(self, sig: Dict[str, float]) -> float:
+        return float(self._run(sig, "standard")[0])
+
+    def score_conditional(self, sig: Dict[str, float]) -> float:
+        return float(self._run(sig, "conditional")[0])
+
+    def score_batch(self, columns: Mapping[str, np.ndarray], mode: str = "standard") -> np.ndarray:
+        """All documents at once: ``columns[name]`` is an array per signal; returns float64 scores.
+
+        float32 columns stay float32 on the device (7 x 4 B per document); any other dtype is
+        uploaded as float64 so that ``z`` sees exactly the caller's value, as in the reference.
+        """
+        if mode not in nat.MODE_CODES:
+            raise ValueError(f"unknown mode {mode!r}")
+        return self._run(columns, mode)

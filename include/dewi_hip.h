@@ -1,0 +1,177 @@
+/*
+ * dewi_hip.h — C ABI of the MI355X-native DEWI scoring-and-retrieval hot path.
+ *
+ * The reference (lexsightllc/DEWI, pure Python) has no FFI: its hot path is the
+ * NumPy code in src/dewi/backends.py (ExactIndex) and src/dewi/scorer.py.  Each
+ * entry point below replaces one block of that code; the citation after "replaces"
+ * is the reference file:line whose result it reproduces.  INTEGRATION.md shows the
+ * ctypes stub a reference maintainer would add to call these from dewi.backends.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only.  No torch / C++ types.
+ *   - Every pointer named d_* is a DEVICE pointer (hipMalloc'd by the caller, e.g.
+ *     torch.Tensor.data_ptr()).  The caller owns every buffer; nothing is retained
+ *     after the call returns and nothing is allocated per call.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).
+ *     All work is enqueued on it; no entry point synchronises the device unless its
+ *     comment says so.
+ *   - Return value: 0 on success, a negative DEWI_ERR_* code on failure;
+ *     dewi_last_error() returns a thread-local, human-readable message.
+ *   - Row indices ("ids") are positions in the embedding matrix; the host layer maps
+ *     them to the reference's string doc ids.
+ */
+#ifndef DEWI_HIP_H
+#define DEWI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DEWI_ABI_VERSION 1
+
+/* status codes */
+#define DEWI_OK 0
+#define DEWI_ERR_INVALID_ARG (-1)   /* NULL pointer, non-positive dim, unknown enum ... */
+#define DEWI_ERR_K_OUT_OF_BOUNDS (-2) /* k > number of rows: the reference raises ValueError here (backends.py:468) */
+#define DEWI_ERR_WORKSPACE (-3)     /* workspace smaller than dewi_*_workspace_bytes() */
+#define DEWI_ERR_HIP (-4)           /* a HIP runtime call failed; see dewi_last_error() */
+#define DEWI_ERR_UNSUPPORTED (-5)   /* shape outside what this build handles */
+
+/* `space` argument (reference: ExactIndex(space=...), backends.py:389-392) */
+#define DEWI_SPACE_COSINE 0 /* query is L2-normalised unless its norm is 0; score = <e, q>            */
+#define DEWI_SPACE_L2 1     /* nothing is normalised; score = -sum((e - q)^2)                       */
+
+/* `mode` argument of dewi_score_f64 (reference: DewiScorer.score / score_conditional) */
+#define DEWI_MODE_STANDARD 0
+#define DEWI_MODE_CONDITIONAL 1
+
+/* number of per-document signals the scorer consumes, in this fixed order
+ * (reference: DewiScorer._components, scorer.py:49-58):
+ *   0 ht_mean  1 ht_q90  2 hi_mean  3 hi_q90  4 I_hat  5 redundancy  6 noise        */
+#define DEWI_NUM_SIGNALS 7
+
+/* One similarity candidate as exchanged between doc-id shards (16 bytes).
+ * `sim` is the raw similarity, `dewi`/`ent` the two fp32 payload values the
+ * re-rank reads (backends.py:450-458), `id` the GLOBAL row index (shard offset
+ * already added) or -1 for padding. */
+typedef struct dewi_candidate {
+  float sim;
+  float dewi;
+  float ent;
+  int32_t id;
+} dewi_candidate;
+
+int dewi_abi_version(void);
+const char* dewi_last_error(void);
+
+/* Device facts the planner uses (compute units, wavefront size); calls hipGetDeviceProperties once. */
+int dewi_device_info(int* out_compute_units, int* out_wavefront, size_t* out_total_mem);
+
+/* ------------------------------------------------------------------------------------------
+ * A1/A2  bulk ingest — replaces ExactIndex.add's `emb / np.linalg.norm(emb)` applied row by
+ * row and ExactIndex.build's np.stack (backends.py:394-412).  Rows with zero norm become NaN,
+ * exactly like the reference (no guard).  src and dst may alias.  fp32 in, fp32 out.
+ * ------------------------------------------------------------------------------------------ */
+int dewi_normalize_rows_f32(const float* d_src, float* d_dst, int64_t n_rows, int dim, void* stream);
+
+/* fp32 -> bf16 (round to nearest even, NaN preserved) for the bf16 corpus of config C3. */
+int dewi_convert_f32_to_bf16(const float* d_src, uint16_t* d_dst, int64_t n_elems, void* stream);
+
+/* payload SoA — replaces the per-candidate Python loop of backends.py:450-458:
+ * dewi32 = fp32(dewi), ent32 = fp32((ht_mean + hi_mean) * 0.5) with the sum/scale in float64. */
+int dewi_payload_soa_f64(const double* d_dewi, const double* d_ht_mean, const double* d_hi_mean,
+                         float* d_dewi32, float* d_ent32, int64_t n_rows, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A3+A4  search — replaces ExactIndex.search (backends.py:414-481) for a batch of queries:
+ *   1. cosine: q <- q / ||q|| unless ||q|| == 0           (:420-424)
+ *   2. sim[i] = <E[i], q>   or   -sum((E[i]-q)^2)          (:431-436)
+ *   3. c = min(2k, n_rows) best rows by sim                (:439-447)   ties: lower row first
+ *   4. adj = fp32(1-eta)*sim + fp32(eta)*dewi32[i]         (:461)       two rounded products, one add
+ *      adj += fp32(pref)*ent32[i]   if pref != 0           (:464-465)
+ *   5. k best by adj, descending                           (:468-481)   ties: higher sim, then lower row
+ * d_E  [n_rows][dim] row-major; d_Q [n_queries][dim] raw (un-normalised) fp32 queries.
+ * d_out_ids [n_queries][k] int64 row indices, d_out_scores [n_queries][k] fp32.
+ * k <= 0 writes nothing and returns DEWI_OK (reference returns []); k > n_rows returns
+ * DEWI_ERR_K_OUT_OF_BOUNDS (reference: ValueError from np.argpartition).
+ * ------------------------------------------------------------------------------------------ */
+size_t dewi_knn_workspace_bytes(int64_t n_rows, int dim, int n_queries, int n_candidates);
+
+int dewi_knn_rerank_f32(const float* d_E, int64_t n_rows, int dim, const float* d_Q, int n_queries,
+                        const float* d_dewi32, const float* d_ent32, int k, double eta, double entropy_pref,
+                        int space, int64_t* d_out_ids, float* d_out_scores, void* d_workspace,
+                        size_t workspace_bytes, void* stream);
+
+/* Same contract with a bf16 corpus (rows already normalised in fp32, then rounded to bf16); queries
+ * arrive as fp32, are normalised in fp32 and rounded to bf16; products are exact, accumulation fp32. */
+int dewi_knn_rerank_bf16(const uint16_t* d_E, int64_t n_rows, int dim, const float* d_Q, int n_queries,
+                         const float* d_dewi32, const float* d_ent32, int k, double eta, double entropy_pref,
+                         int space, int64_t* d_out_ids, float* d_out_scores, void* d_workspace,
+                         size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Doc-id sharding (new; the reference is single-process).  Steps 1-3 on one shard, emitting the
+ * shard's best `n_candidates` rows per query as dewi_candidate records sorted by (sim desc, id
+ * asc); records past min(n_candidates, n_rows) are padding (id = -1, sim = -inf).
+ * `id_offset` is added to the local row index.  d_out [n_queries][n_candidates].
+ * elem_type: 0 = fp32 corpus, 1 = bf16 corpus.
+ * ------------------------------------------------------------------------------------------ */
+int dewi_knn_candidates(const void* d_E, int elem_type, int64_t n_rows, int dim, const float* d_Q,
+                        int n_queries, const float* d_dewi32, const float* d_ent32, int n_candidates,
+                        int space, int64_t id_offset, dewi_candidate* d_out, void* d_workspace,
+                        size_t workspace_bytes, void* stream);
+
+/* Steps 3-5 over the concatenation of `n_lists` candidate lists per query (the all-gather result,
+ * laid out [n_lists][n_queries][list_len]): global top-`n_candidates` by (sim desc, id asc), then
+ * the blend and the top-k exactly as dewi_knn_rerank_f32.  Needs no workspace. */
+int dewi_merge_rerank(const dewi_candidate* d_lists, int n_lists, int n_queries, int list_len,
+                      int n_candidates, int k, double eta, double entropy_pref, int64_t* d_out_ids,
+                      float* d_out_scores, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A6  robust statistics — replaces scorer.RobustStats.fit (scorer.py:18-26) for n_signals
+ * columns of n fp32 values each, stored SoA: column s starts at d_S + s*ld.
+ *   med[s] = np.median(col)            exact fp32 order statistic; even n: fp32 (a+b)/2
+ *   mad[s] = np.median(|col - med[s]|) subtraction in fp32
+ * Any NaN in a column makes its median NaN (NumPy semantics).  The `mad or 1e-8` substitution is
+ * host-side float64 logic and stays in the caller.  Outputs are device fp32 arrays [n_signals].
+ * ------------------------------------------------------------------------------------------ */
+size_t dewi_robust_fit_workspace_bytes(int n_signals);
+
+int dewi_robust_fit_f32(const float* d_S, int64_t n, int64_t ld, int n_signals, float* d_med, float* d_mad,
+                        void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A7+A8  DEWI score — replaces RobustStats.z, DewiScorer._components, score, score_conditional
+ * (scorer.py:28-31, 49-89), float64 arithmetic in the reference's operation order:
+ *   z = (x - med) / (1.4826 * mad);  Ht = .5(z0+z1)  Hi = .5(z2+z3)  I = z4  R = z5  N = z6
+ *   standard:    U = at*Ht + ai*Hi - am*I - ar*R - an*N
+ *   conditional: U = at*(Ht-I) + ai*(Hi-I) - ar*R - an*N
+ *   out = 1 / (1 + exp(-clip(U, -delta, delta)))
+ * d_S: DEWI_NUM_SIGNALS columns (fixed order above), column s at element offset s*ld, of fp32
+ * (signals_are_f64 = 0) or float64 (= 1) values.  med/mad/weights are HOST arrays
+ * (7, 7 and 5 doubles: alpha_t, alpha_i, alpha_m, alpha_r, alpha_n).  d_out: n float64 values;
+ * d_out32 (may be NULL): the same rounded to fp32, ready to be the index's dewi32 column.
+ * ------------------------------------------------------------------------------------------ */
+int dewi_score_f64(const void* d_S, int signals_are_f64, int64_t n, int64_t ld, const double* med,
+                   const double* mad, const double* weights, double delta, int mode, double* d_out,
+                   float* d_out32, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Measurement hooks (bench.py): when enabled, every dewi_knn_* call brackets its corpus-scan
+ * kernel with hipEvents on `stream`; dewi_timing_read synchronises those events and returns the
+ * mean scan-kernel duration in milliseconds and the number of launches averaged, then resets.
+ * ------------------------------------------------------------------------------------------ */
+int dewi_timing_enable(int enable);
+int dewi_timing_read(double* out_mean_scan_ms, int* out_launches);
+
+/* Launch-shape overrides for tuning sweeps (0 = planner default). */
+int dewi_tuning_set(int scan_blocks, int rows_per_iter, int nontemporal);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEWI_HIP_H */

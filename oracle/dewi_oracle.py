@@ -137,13 +137,18 @@ def search(E: np.ndarray, query: np.ndarray, dewi32: np.ndarray, ent32: np.ndarr
 # every relevant gap exceeds a noise threshold.
 # ---------------------------------------------------------------------------
 def decision_gaps(E: np.ndarray, query: np.ndarray, dewi32: np.ndarray, ent32: np.ndarray, k: int,
-                  eta: float, entropy_pref: float = 0.0, space: str = "cosine"
+                  eta: float, entropy_pref: float = 0.0, space: str = "cosine", exact: bool = True
                   ) -> Tuple[float, float]:
     """(similarity gap between rank c and c+1, smallest adjacent adjusted-score
-    gap among ranks 1..k+1), all computed in float64 from the fp32 inputs."""
-    q = prepare_query(query, space).astype(np.float64)
-    E64 = E.astype(np.float64)
-    s = E64 @ q if space == "cosine" else -np.sum((E64 - q[None, :]) ** 2, axis=1)
+    gap among ranks 1..k+1), computed in float64 from the fp32 inputs.  ``exact=False``
+    takes the similarities from the fp32 product instead (for corpora where an f64 copy of
+    the matrix is too expensive); the gaps then carry ~1e-7 of noise themselves."""
+    if exact:
+        q = prepare_query(query, space).astype(np.float64)
+        E64 = E.astype(np.float64)
+        s = E64 @ q if space == "cosine" else -np.sum((E64 - q[None, :]) ** 2, axis=1)
+    else:
+        s = similarities(E, prepare_query(query, space), space).astype(np.float64)
     n = s.shape[0]
     c = min(2 * k, n)
     order = np.argsort(-s, kind="stable")

@@ -1,0 +1,113 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol the header
+declares, the host-side data contract behaves like the reference's, and the product
+path refuses to run without a GPU instead of falling back."""
+import ctypes
+import json
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol():
+    from dewi import _native as nat
+    header = (REPO / "include" / "dewi_hip.h").read_text()
+    declared = set(re.findall(r"\b(dewi_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(nat.EXPORTED_SYMBOLS), declared ^ set(nat.EXPORTED_SYMBOLS)
+    lib = nat.load_library(require_gpu=False)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.dewi_abi_version() == nat.ABI_VERSION
+    assert ctypes.sizeof(nat.DewiCandidate) == 16
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from dewi import _native as nat
+    from dewi.index import ExactIndex, Payload
+    from dewi.scorer import DewiScorer
+    idx = ExactIndex(dim=4)
+    idx.add("a", np.ones(4, np.float32), Payload())
+    with pytest.raises(nat.NativeLibraryError):
+        idx.build()
+    with pytest.raises(nat.NativeLibraryError):
+        idx.search(np.ones(4, np.float32), k=1)
+    with pytest.raises(nat.NativeLibraryError):
+        DewiScorer().fit_stats([{"x": 1.0}])
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = REPO / "dewi-design-for-an-entropy-weighted-index-for-text-image-corpora_amd"
+    for path in list(pkg.rglob("*.py")) + list(pkg.rglob("*.hip")) + list(pkg.rglob("*.cpp")) + list(pkg.rglob("*.hpp")):
+        text = path.read_text()
+        assert "dewi_oracle" not in text and "oracle/" not in text, path
+
+
+def test_payload_serialization():
+    """tests/test_index.py:73-101 of the reference."""
+    from dewi.index import Payload
+    p = Payload(dewi=0.5, ht_mean=1.2, ht_q90=1.8, hi_mean=0.8, hi_q90=1.2, I_hat=0.6, redundancy=0.1, noise=0.05)
+    d = p.to_dict()
+    assert isinstance(d, dict) and "dewi" in d and list(d) == ["dewi", "ht_mean", "ht_q90", "hi_mean", "hi_q90",
+                                                               "I_hat", "redundancy", "noise"]
+    assert Payload.from_dict(d).dewi == p.dewi
+    b = p.to_bytes()
+    assert isinstance(b, bytes) and Payload.from_bytes(b) == p
+    assert Payload.from_dict({"dewi": "0.25", "extra": 1}) == Payload(dewi=0.25)     # extras ignored, float() cast
+    assert Payload() == Payload(0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0)
+
+
+def test_payload_codec_matches_reference_files(golden_dir):
+    from dewi.types import Payload
+    lines = (golden_dir / "g5_exact_index" / "payloads.jsonl").read_text().splitlines()
+    for line in lines:
+        rec = json.loads(line)
+        p = Payload.from_dict(rec["payload"])
+        assert json.dumps({"doc_id": rec["doc_id"], "payload": p.to_dict()}) == line
+
+
+def test_weights_defaults_and_columns():
+    from dewi.types import Payload, Weights, payload_columns, payloads_from_columns
+    w = Weights()
+    assert (w.alpha_t, w.alpha_i, w.alpha_m, w.alpha_r, w.alpha_n, w.delta) == (1.0, 1.0, 1.0, 1.0, 1.0, 3.0)
+    assert w.as_vector().tolist() == [1.0] * 5
+    ps = [Payload(dewi=i / 10, ht_mean=i, hi_mean=2 * i) for i in range(5)]
+    cols = payload_columns(ps)
+    assert cols["hi_mean"].tolist() == [0, 2, 4, 6, 8] and cols["dewi"].dtype == np.float64
+    assert payloads_from_columns(cols) == ps
+
+
+def test_exact_index_host_side_contract(tmp_path):
+    """Everything ExactIndex/DewiIndex do before touching the device."""
+    from dewi.index import DewiIndex, ExactIndex, IndexBackend, Payload
+    idx = ExactIndex(dim=4, space="cosine")
+    assert idx.dim == 4 and idx.space == "cosine" and idx._doc_ids == [] and idx._payloads == {} and not idx._is_trained
+    with pytest.raises(ValueError, match=r"Expected embedding of shape \(4,\), got \(5,\)"):
+        idx.add("x", np.zeros(5, np.float32), Payload())
+    p = Payload(dewi=0.3)
+    idx.add("a", np.arange(4, dtype=np.float64), p)
+    assert idx._doc_ids == ["a"] and idx._payloads["a"] is p and idx._embeddings[0].dtype == np.float32
+    di = DewiIndex(dim=4, backend="definitely-not-a-backend")
+    assert isinstance(di._backend, ExactIndex) and di.rerank_eta == 0.25 and di.entropy_pref == 0.0
+    assert IndexBackend.from_str("exact") is IndexBackend.EXACT and len(di) == 0
+    # empty index persists in the reference's format
+    ExactIndex(dim=3).save(tmp_path / "e")
+    meta = json.loads((tmp_path / "e" / "metadata.json").read_text())
+    assert meta == {"dim": 3, "space": "cosine", "doc_ids": [], "normalize": True, "is_trained": False,
+                    "num_embeddings": 0}
+    assert not (tmp_path / "e" / "embeddings.npy").exists()
+
+
+def test_loading_reference_saved_index_is_host_only(golden_dir):
+    from dewi.index import DewiIndex, ExactIndex
+    ex = ExactIndex.load(golden_dir / "g5_exact_index")
+    assert ex.dim == 8 and ex._doc_ids == [f"id-{i}" for i in range(6)] and len(ex._payloads) == 6
+    assert isinstance(ex._embeddings, np.ndarray) and ex._embeddings.shape == (6, 8)
+    di = DewiIndex.load(golden_dir / "g5_dewi_index")
+    assert len(di) == 6 and di.get_metadata("id-2") == {"source": "file2.txt"} and di.get_metadata("id-1") is None
+    assert np.allclose(np.linalg.norm(di.get_embedding("id-4")), 1.0, atol=1e-6)

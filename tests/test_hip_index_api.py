@@ -1,0 +1,197 @@
+"""The reference's own index tests (tests/test_index.py, test_index_delegation.py,
+test_index_roundtrip.py), restated against the MI355X drop-in: same fixtures, same
+assertions, plus persistence interchange with directories the reference itself saved."""
+import json
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+DIM, N_DOCS, N_QUERIES, K = 128, 100, 5, 10
+
+
+def _fixtures():
+    from dewi.index import Payload
+    rs = np.random.RandomState(42)
+    embs = rs.randn(N_DOCS, DIM).astype(np.float32)
+    embs /= np.linalg.norm(embs, axis=1, keepdims=True)
+    pays = [Payload(dewi=float(np.clip(rs.beta(2, 2), 0, 1)), ht_mean=float(rs.gamma(2, 0.5)),
+                    ht_q90=float(rs.gamma(2, 0.5) * 1.5), hi_mean=float(rs.gamma(2, 0.3)),
+                    hi_q90=float(rs.gamma(2, 0.3) * 1.5), I_hat=float(rs.beta(2, 2)),
+                    redundancy=float(rs.beta(1, 5)), noise=float(rs.beta(1, 10))) for _ in range(N_DOCS)]
+    ids = [f"doc_{i}" for i in range(N_DOCS)]
+    qs = rs.randn(N_QUERIES, DIM).astype(np.float32)
+    qs /= np.linalg.norm(qs, axis=1, keepdims=True)
+    return ids, embs, pays, qs
+
+
+def test_exact_index():
+    from dewi.index import ExactIndex, Payload
+    ids, embs, pays, qs = _fixtures()
+    index = ExactIndex(dim=DIM, space="cosine")
+    for d, e, p in zip(ids, embs, pays):
+        index.add(d, e, p)
+    index.build()
+    for q in qs:
+        results = index.search(q, k=K)
+        assert len(results) == K
+        scores = [r[1] for r in results]
+        assert all(scores[i] >= scores[i + 1] for i in range(len(scores) - 1))
+        for doc_id, score, payload in results:
+            assert doc_id in ids and isinstance(score, float) and isinstance(payload, Payload)
+    with pytest.raises(ValueError, match="Expected embedding of shape"):
+        index.add("bad", np.zeros(DIM + 1, np.float32), Payload())
+    with pytest.raises(ValueError, match="No embeddings"):
+        ExactIndex(dim=4).build()
+
+
+def test_ann_backends_absent_like_reference_without_libs():
+    from dewi.index import FAISSIndex, HNSWIndex, IndexBackend, _HAS_FAISS, _HAS_HNSW
+    assert not _HAS_FAISS and not _HAS_HNSW
+    with pytest.raises(ImportError):
+        HNSWIndex(dim=8)
+    with pytest.raises(ImportError):
+        FAISSIndex(dim=8)
+    assert IndexBackend.from_str("auto") is IndexBackend.EXACT
+    with pytest.raises(KeyError):
+        IndexBackend.from_str("nope")
+
+
+def test_dewi_index_factory():
+    from dewi.index import DewiIndex
+    ids, embs, pays, qs = _fixtures()
+    index = DewiIndex(dim=DIM, space="cosine")        # backend="auto", use_ann=True -> exact fallback
+    for d, e, p in zip(ids[:20], embs[:20], pays[:20]):
+        index.add(d, e, p)
+    index.build()
+    results = index.search(qs[0], k=K)
+    assert 0 < len(results) <= K
+    assert len(index) == 20 and index.get_payload("doc_3") is pays[3]
+    assert np.allclose(index.get_embedding("doc_3"), embs[3], atol=1e-6) and index.get_embedding("nope") is None
+    with pytest.raises(ValueError, match=r"Expected query shape \(128,\)"):
+        index.search(np.zeros((1, DIM), np.float32))
+
+
+def test_index_persistence(tmp_path):
+    from dewi.index import ExactIndex, Payload
+    ids, embs, pays, qs = _fixtures()
+    index = ExactIndex(dim=DIM, space="cosine")
+    for d, e, p in zip(ids[:10], embs[:10], pays[:10]):
+        index.add(d, e, p)
+    index.build()
+    before = index.search(qs[0], k=5)
+    save_dir = tmp_path / "test_index"
+    index.save(save_dir)
+    assert (save_dir / "metadata.json").exists() and (save_dir / "payloads.jsonl").exists()
+    assert (save_dir / "embeddings.npy").exists()
+    loaded = ExactIndex.load(save_dir)
+    assert loaded.dim == DIM and len(loaded._doc_ids) == 10 and set(loaded._doc_ids) == set(ids[:10])
+    for d in ids[:10]:
+        assert d in loaded._payloads and isinstance(loaded._payloads[d], Payload)
+    results = loaded.search(qs[0], k=5)
+    assert len(results) == 5
+    assert [r[0] for r in results] == [r[0] for r in before]
+    assert [r[1] for r in results] == [r[1] for r in before]        # stored rows are not re-normalised
+
+
+def test_entropy_preference():
+    from dewi.index import ExactIndex, Payload
+    index = ExactIndex(dim=DIM, space="cosine")
+    n = 50
+    rs = np.random.RandomState(42)
+    embs = rs.randn(n, DIM).astype(np.float32)
+    embs /= np.linalg.norm(embs, axis=1, keepdims=True)
+    for i in range(n):
+        ent = float(i / n)
+        index.add(f"doc_{i}", embs[i], Payload(dewi=0.5, ht_mean=ent, ht_q90=ent * 1.5, hi_mean=ent, hi_q90=ent * 1.5,
+                                               I_hat=0.5, redundancy=0.1, noise=0.05))
+    index.build()
+    q = np.ones(DIM, np.float32) / np.sqrt(DIM)
+
+    def avg_ent(res):
+        return np.mean([(r[2].ht_mean + r[2].hi_mean) / 2 for r in res])
+
+    pos, neu, neg = (avg_ent(index.search(q, k=10, entropy_pref=p)) for p in (1.0, 0.0, -1.0))
+    assert pos >= neu >= neg
+
+
+def test_dewi_reranking():
+    from dewi.index import ExactIndex, Payload
+    index = ExactIndex(dim=DIM, space="cosine")
+    n = 50
+    rs = np.random.RandomState(42)
+    embs = rs.randn(n, DIM).astype(np.float32)
+    embs /= np.linalg.norm(embs, axis=1, keepdims=True)
+    for i in range(n):
+        index.add(f"doc_{i}", embs[i], Payload(dewi=float(i / n), ht_mean=1.0, ht_q90=1.5, hi_mean=0.8, hi_q90=1.2,
+                                               I_hat=0.5, redundancy=0.1, noise=0.05))
+    index.build()
+    q = np.ones(DIM, np.float32) / np.sqrt(DIM)
+
+    def avg_dewi(res):
+        return np.mean([r[2].dewi for r in res])
+
+    hi, mid, lo = (avg_dewi(index.search(q, k=10, eta=e)) for e in (1.0, 0.5, 0.0))
+    assert hi >= mid >= lo
+
+
+def test_index_delegation_shapes_and_no_error():
+    from dewi.index import DewiIndex
+    from dewi.types import Payload
+    dim = 16
+    idx = DewiIndex(dim=dim, backend="auto", use_ann=False)
+    for j in range(10):
+        idx.add(f"id-{j}", np.random.RandomState(100 + j).randn(dim).astype(np.float32), Payload(dewi=0.5))
+    idx.build()
+    q = np.zeros(dim, np.float32)
+    q[0] = 1.0
+    assert len(idx.search(q, k=5, eta=0.0, entropy_pref=0.0)) == 5
+
+
+def test_index_roundtrip(tmp_path):
+    from dewi.index import DewiIndex, Payload
+    dim = 8
+    idx = DewiIndex(dim=dim, backend="auto", use_ann=False)
+    for i in range(5):
+        idx.add(f"id-{i}", np.random.RandomState(42 + i).randn(dim).astype(np.float32), payload=Payload())
+    idx.build()
+    q = np.zeros(dim, np.float32)
+    q[0] = 1.0
+    res = idx.search(q, k=3)
+    assert len(res) == 3
+    idx.save(tmp_path / "idx")
+    re = DewiIndex.load(tmp_path / "idx")
+    res2 = re.search(q, k=3)
+    assert [r[0] for r in res2] == [r[0] for r in res]
+
+
+def test_loads_directories_saved_by_the_reference(golden_dir):
+    """G5: ExactIndex.save / DewiIndex.save output of the reference itself loads and searches."""
+    from dewi.index import DewiIndex, ExactIndex
+    exp = json.loads((golden_dir / "g5_expected.json").read_text())
+    q = np.array(exp["query"], np.float32)
+    ex = ExactIndex.load(golden_dir / "g5_exact_index")
+    got = ex.search(q, k=3, eta=0.5)
+    assert [r[0] for r in got] == [r[0] for r in exp["exact_k3_eta0.5"]]
+    assert np.allclose([r[1] for r in got], [r[1] for r in exp["exact_k3_eta0.5"]], atol=1e-6)
+    di = DewiIndex.load(golden_dir / "g5_dewi_index")
+    assert di.rerank_eta == 0.4 and di.entropy_pref == 0.1 and di.get_metadata("id-0") == {"source": "file0.txt"}
+    got = di.search(q, k=3)
+    assert [r[0] for r in got] == [r[0] for r in exp["dewi_k3_defaults"]]
+    assert np.allclose([r[1] for r in got], [r[1] for r in exp["dewi_k3_defaults"]], atol=1e-6)
+
+
+def test_batch_api_equals_single_queries():
+    from dewi.index import DewiIndex
+    ids, embs, pays, qs = _fixtures()
+    index = DewiIndex(dim=DIM, use_ann=False)
+    index.add_batch(ids, embs, pays)
+    batched = index.search_batch(qs, k=K, eta=0.3)
+    for q, res in zip(qs, batched):
+        single = index.search(q, k=K, eta=0.3)
+        assert [(r[0], r[1]) for r in single] == [(r[0], r[1]) for r in res]
+        assert all(a[2] is b[2] for a, b in zip(single, res))
+    index.add("late", embs[0], pays[0])            # add after build -> lazily rebuilt
+    assert index.search(embs[0], k=2, eta=0.0)[0][0] in ("doc_0", "late")
+    assert len(index) == N_DOCS + 1

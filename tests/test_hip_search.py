@@ -1,0 +1,225 @@
+"""GPU parity tests of the search path (A1-A5), all through the C ABI.
+
+Each test builds the same seeded inputs for the HIP path and the CPU oracle
+(oracle/dewi_oracle.py, pinned to the reference by tests/test_oracle_golden.py) and
+compares with tests/parity.py; golden vectors produced by the reference itself are
+checked directly as well.
+"""
+import json
+
+import numpy as np
+import pytest
+
+import dewi_oracle as orc
+from parity import check_batch, compare_query
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine():
+    from dewi import _engine
+    return _engine
+
+
+def _corpus(E_raw, cols, space="cosine", normalize=None):
+    eng = _engine()
+    return eng.DeviceCorpus.from_host(E_raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"], space, normalize=normalize)
+
+
+def test_library_reports_mi355x():
+    import ctypes
+    from dewi import _native as nat
+    lib = nat.load_library()
+    cu, wave, mem = ctypes.c_int(), ctypes.c_int(), ctypes.c_size_t()
+    nat.check(lib.dewi_device_info(ctypes.byref(cu), ctypes.byref(wave), ctypes.byref(mem)))
+    assert wave.value == 64 and cu.value >= 64 and mem.value > (1 << 30)
+
+
+def test_normalize_rows_matches_oracle():
+    rs = np.random.RandomState(0)
+    for n, d in ((7, 8), (100, 128), (33, 10), (257, 768), (5, 1000)):
+        raw = (rs.randn(n, d) * rs.uniform(0.1, 10)).astype(np.float32)
+        cols = orc.synth_payload_columns(n, seed=1)
+        c = _corpus(raw, cols)
+        got = c.emb.cpu().numpy()
+        want = orc.build_matrix(raw)
+        assert np.allclose(got, want, rtol=0, atol=2e-7), (n, d, np.abs(got - want).max())
+        assert np.allclose(np.linalg.norm(got.astype(np.float64), axis=1), 1.0, atol=1e-6)
+    # zero row -> NaN row, like the reference (no guard)
+    raw = rs.randn(4, 16).astype(np.float32)
+    raw[2] = 0
+    got = _corpus(raw, orc.synth_payload_columns(4, seed=1)).emb.cpu().numpy()
+    assert np.all(np.isnan(got[2])) and not np.any(np.isnan(got[[0, 1, 3]]))
+
+
+def test_payload_soa_bit_exact():
+    cols = orc.synth_payload_columns(1000, seed=9)
+    c = _corpus(np.random.RandomState(1).randn(1000, 8).astype(np.float32), cols)
+    d32, e32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    assert np.array_equal(c.dewi32.cpu().numpy(), d32)
+    assert np.array_equal(c.ent32.cpu().numpy(), e32)
+
+
+def test_g1_reference_golden_through_the_api(golden):
+    """tests/test_index.py shape, via ExactIndex.add/build/search, against the reference's outputs."""
+    from dewi.index import ExactIndex, Payload
+    g = golden("g1_test_index_shape.npz")
+    n = g["E"].shape[0]
+    idx = ExactIndex(dim=g["E"].shape[1], space="cosine")
+    pay = [Payload(**{k: float(g[f"p_{k}"][i]) for k in orc.PAYLOAD_KEYS}) for i in range(n)]
+    for i in range(n):
+        idx.add(f"doc_{i}", g["E"][i], pay[i])
+    idx.build()
+    k = int(g["k"])
+    dewi32, ent32 = orc.payload_soa(g["p_dewi"], g["p_ht_mean"], g["p_hi_mean"])
+    mism = 0
+    for a, eta in enumerate(g["etas"]):
+        for b, pref in enumerate(g["prefs"]):
+            for j, q in enumerate(g["Q"]):
+                res = idx.search(q, k=k, eta=float(eta), entropy_pref=float(pref))
+                assert len(res) == k
+                assert all(isinstance(r[0], str) and isinstance(r[1], float) and r[2] is pay[int(r[0][4:])] for r in res)
+                ids = np.array([int(r[0][4:]) for r in res])
+                sc = np.array([r[1] for r in res], np.float32)
+                decisive, msg = compare_query(g["stored"], q, dewi32, ent32, k, float(eta), float(pref), "cosine", ids, sc)
+                assert msg is None, (eta, pref, j, msg)
+                if decisive:
+                    assert np.array_equal(ids, g["ids"][a, b, j])
+                    assert np.allclose(sc, g["scores"][a, b, j], rtol=0, atol=1e-5)
+                else:
+                    mism += 1
+    assert mism <= 4
+
+
+def test_g2_c1_10k_768_golden(golden):
+    """Config C1 (10K x 768, k=10, eta=0.3): fast row-per-wave kernel vs the reference's outputs."""
+    g = golden("g2_c1_10k_768.npz")
+    n, d, k, eta = int(g["n"]), int(g["d"]), int(g["k"]), float(g["eta"])
+    raw = orc.synth_corpus(n, d, seed=int(g["corpus_seed"]))
+    cols = orc.synth_payload_columns(n, seed=int(g["corpus_seed"]))
+    Q = orc.synth_queries(g["ids"].shape[0], d, seed=int(g["query_seed"]))
+    c = _corpus(raw, cols)
+    ids, sc = c.search(Q, k, eta, 0.0)            # one batched call (NQ=4 passes)
+    ids1 = np.stack([c.search(Q[j], k, eta, 0.0)[0][0] for j in range(8)])   # batch-1 kernel
+    assert np.array_equal(ids1, ids[:8])
+    E = orc.build_matrix(raw)
+    dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    excluded = check_batch(E, Q, dewi32, ent32, k, eta, 0.0, "cosine", ids, sc)
+    exact = sum(int(np.array_equal(ids[j], g["ids"][j])) for j in range(Q.shape[0]))
+    assert exact >= Q.shape[0] - excluded
+    assert np.max(np.abs(sc[ids == g["ids"]] - g["scores"][ids == g["ids"]])) <= 1e-5
+
+
+def test_g3_edge_cases(golden, golden_dir):
+    g = golden("g3_edge_cases.npz")
+    meta = json.loads((golden_dir / "g3_edge_cases.json").read_text())
+    cols = {k: g[f"p_{k}"] for k in orc.PAYLOAD_KEYS}
+    dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    c_cos = _corpus(g["E"], cols, "cosine")
+    c_l2 = _corpus(g["E"], cols, "l2")
+    assert np.array_equal(c_l2.emb.cpu().numpy(), g["E"])        # l2 keeps raw rows
+    names = sorted({key.split("__")[0] for key in g.files if "__" in key})
+    for name in names:
+        q, k = g[f"{name}__q"], int(g[f"{name}__k"])
+        eta, pref = float(g[f"{name}__eta"]), float(g[f"{name}__pref"])
+        space = "l2" if name.startswith("l2") else "cosine"
+        corpus = c_l2 if space == "l2" else c_cos
+        E = g["E"] if space == "l2" else g["stored_cos"]
+        ids, sc = corpus.search(q, k, eta, pref)
+        if name == "zero_query":
+            # every similarity is exactly 0: the reference's ids are an introselect artefact; scores are not
+            assert np.allclose(np.sort(sc[0]), np.sort(g[f"{name}__scores"]), atol=1e-6)
+            continue
+        decisive, msg = compare_query(E, q, dewi32, ent32, k, eta, pref, space, ids[0], sc[0])
+        assert msg is None, (name, msg)
+        if decisive:
+            assert np.array_equal(ids[0], g[f"{name}__ids"]), name
+            tol = 1e-5 * max(1.0, float(np.abs(g[f"{name}__scores"]).max()))
+            assert np.allclose(sc[0], g[f"{name}__scores"], rtol=0, atol=tol), name
+    # k > N -> ValueError with NumPy's message; k == 0 -> empty
+    with pytest.raises(ValueError, match="out of bounds"):
+        c_cos.search(g["k_eq_n__q"], meta["n"] + 1, 0.3, 0.0)
+    ids, sc = c_cos.search(g["k_eq_n__q"], 0, 0.3, 0.0)
+    assert ids.shape == (1, 0) and sc.shape == (1, 0)
+
+
+@pytest.mark.parametrize("dim", [8, 10, 16, 100, 128, 256, 260, 512, 768, 1024, 1536, 2048])
+def test_dimension_sweep_vs_oracle(dim):
+    """Every kernel variant: fast path (dim = 256*U), vectorised generic, scalar generic (odd dims)."""
+    n = 3001 if dim <= 1024 else 1500
+    raw = orc.synth_corpus(n, dim, seed=dim)
+    cols = orc.synth_payload_columns(n, seed=dim)
+    Q = orc.synth_queries(5, dim, seed=dim + 1)      # 5 = one NQ=4 pass + one NQ=1 pass
+    c = _corpus(raw, cols)
+    E = c.emb.cpu().numpy()                             # same stored rows on both sides
+    dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    for k, eta, pref in ((1, 0.3, 0.0), (10, 0.3, 0.0), (10, 0.7, -0.5), (100, 0.25, 0.3), (150, 0.5, 0.0)):
+        ids, sc = c.search(Q, k, eta, pref)          # k=150 -> c=300 > 256: dense-key path
+        check_batch(E, Q, dewi32, ent32, k, eta, pref, "cosine", ids, sc, max_excluded_frac=0.4)
+
+
+@pytest.mark.parametrize("dim", [16, 100, 768])
+def test_l2_space_vs_oracle(dim):
+    n = 2000
+    rs = np.random.RandomState(dim)
+    raw = (rs.randn(n, dim) * 0.5).astype(np.float32)
+    cols = orc.synth_payload_columns(n, seed=3)
+    Q = (rs.randn(5, dim) * 0.5).astype(np.float32)
+    c = _corpus(raw, cols, "l2")
+    dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    ids, sc = c.search(Q, 10, 0.3, 0.0)
+    check_batch(raw, Q, dewi32, ent32, 10, 0.3, 0.0, "l2", ids, sc, max_excluded_frac=0.4)
+
+
+def test_ties_prefer_lower_row_and_zero_query():
+    """Duplicate rows tie exactly; the device order is (sim desc, row asc) — deterministic, unlike
+    the reference's introselect artefact (SURVEY.md §7 hard part (i))."""
+    rs = np.random.RandomState(5)
+    base = rs.randn(4, 256).astype(np.float32)
+    raw = np.concatenate([base, base, base], axis=0)           # rows i, i+4, i+8 identical
+    cols = {k: np.zeros(12) for k in orc.PAYLOAD_KEYS}
+    c = _corpus(raw, cols)
+    ids, sc = c.search(base[1], 3, 0.0, 0.0)
+    assert ids[0].tolist() == [1, 5, 9]
+    assert np.allclose(sc[0], 1.0, atol=1e-6)
+    ids, sc = c.search(np.zeros(256, np.float32), 5, 0.0, 0.0)  # all sims exactly 0
+    assert ids[0].tolist() == [0, 1, 2, 3, 4] and np.all(sc[0] == 0)
+
+
+def test_nan_rows_rank_first_like_numpy():
+    """A zero-norm row becomes NaN at build (reference has no guard); NumPy's partition ranks NaN
+    as the largest value, so the reference returns such rows first with a NaN score."""
+    rs = np.random.RandomState(6)
+    raw = rs.randn(300, 256).astype(np.float32)
+    raw[17] = 0
+    cols = orc.synth_payload_columns(300, seed=6)
+    c = _corpus(raw, cols)
+    ids, sc = c.search(rs.randn(256).astype(np.float32), 5, 0.3, 0.0)
+    assert ids[0, 0] == 17 and np.isnan(sc[0, 0]) and not np.any(np.isnan(sc[0, 1:]))
+
+
+def test_sharded_candidates_and_merge_equal_single_device():
+    """Row (e): per-shard top-2k records + merge == the unsharded search (same GPU, 3 ragged shards)."""
+    eng = _engine()
+    import torch
+    n, d, k, eta, pref = 5000, 768, 10, 0.3, 0.2
+    raw = orc.synth_corpus(n, d, seed=77)
+    cols = orc.synth_payload_columns(n, seed=77)
+    Q = orc.synth_queries(6, d, seed=78)
+    whole = _corpus(raw, cols)
+    ids_ref, sc_ref = whole.search(Q, k, eta, pref)
+    bounds = [0, 1700, 1715, n]                       # middle shard has only 15 rows (< 2k = 20)
+    c = min(2 * k, n)
+    lists = []
+    qd = torch.from_numpy(Q).cuda()
+    for s in range(3):
+        lo, hi = bounds[s], bounds[s + 1]
+        sub = {key: v[lo:hi] for key, v in cols.items()}
+        shard = eng.DeviceCorpus.from_host(raw[lo:hi], sub["dewi"], sub["ht_mean"], sub["hi_mean"], "cosine", id_offset=lo)
+        lists.append(shard.candidates_device(qd, c))
+    recs = eng.records_to_numpy(lists[1])
+    assert np.all(recs["id"][:, 15:] == -1) and np.all(recs["id"][:, :15] >= 1700)
+    assert np.all(np.diff(eng.records_to_numpy(lists[0])["sim"], axis=1) <= 0)
+    ids, sc = eng.merge_rerank_device(torch.stack(lists), c, k, eta, pref)
+    assert np.array_equal(ids.cpu().numpy(), ids_ref)
+    assert np.array_equal(sc.cpu().numpy(), sc_ref)
