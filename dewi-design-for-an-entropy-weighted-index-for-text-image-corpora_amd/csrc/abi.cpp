@@ -178,7 +178,7 @@ int knn_rerank_impl(const void* d_E, int elem_type, int64_t n_rows, int dim, con
   if (rc) return rc;
   const dewi::RerankParams rp = make_rerank(eta, pref);
   hipError_t e = dewi::launch_select_rerank(reinterpret_cast<const uint64_t*>(ws + L.keys_off), L.plan.keys_per_query,
-                                            n_queries, c, k, rp, d_dewi32, d_ent32, 0, d_out_ids, d_out_scores, nullptr,
+                                            L.plan.slots == 1 ? L.plan.n_lists : 0, n_queries, c, k, rp, d_dewi32, d_ent32, 0, d_out_ids, d_out_scores, nullptr,
                                             stream);
   if (e != hipSuccess) return hip_fail(e, "select_rerank launch");
   return DEWI_OK;
@@ -278,6 +278,7 @@ int dewi_knn_candidates(const void* d_E, int elem_type, int64_t n_rows, int dim,
   // The select kernel writes n_candidates records per query; when the shard has fewer rows than
   // that, it selects every row and pads the tail (id = -1, sim = -inf).
   hipError_t e = dewi::launch_select_rerank(reinterpret_cast<const uint64_t*>(ws + L.keys_off), L.plan.keys_per_query,
+                                            (L.plan.slots == 1 && c_local == n_candidates) ? L.plan.n_lists : 0,
                                             n_queries, n_candidates, 0, rp, d_dewi32, d_ent32, id_offset, nullptr,
                                             nullptr, d_out, stream);
   if (e != hipSuccess) return hip_fail(e, "select (candidates) launch");

@@ -24,7 +24,7 @@ namespace dewi {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kSlots = kMaxListCandidates / kWave;  // 4 key registers per lane per query
+constexpr int kMaxSlots = kMaxListCandidates / kWave;  // up to 4 key registers per lane per query
 
 template <bool NT>
 __device__ __forceinline__ f32x4 load_x4(const f32x4* p) {
@@ -36,6 +36,7 @@ __device__ __forceinline__ f32x4 load_x4(const f32x4* p) {
 // Per-wave top-c list.  Position p = slot*64 + lane is active when p < c.  `thr` is the smallest
 // active key (the entry a better candidate replaces), `thr_s` its score for the cheap test.
 // ---------------------------------------------------------------------------------------------
+template <int kSlots>
 struct WaveList {
   uint64_t key[kSlots];
   uint64_t thr;
@@ -76,6 +77,28 @@ struct WaveList {
   }
 };
 
+// Block-level merge of the four per-wave lists (single-slot lists, c <= 64): every wave drops its
+// c keys into LDS, each thread ranks one key against all 4c (broadcast reads), and the c best
+// leave the kernel already sorted descending.  Empty keys tie at 0 and are ordered by position.
+__device__ __forceinline__ void block_merge_store(const WaveList<1>& lst, uint64_t* __restrict__ sh,
+                                                  uint64_t* __restrict__ dst, int c, int lane, int wave_in_block) {
+  constexpr int kWavesPerBlock = kScanThreads / kWave;
+  __syncthreads();  // sh may still be read by the previous query's merge
+  if (lane < c) sh[wave_in_block * c + lane] = lst.key[0];
+  __syncthreads();
+  const int total = kWavesPerBlock * c;  // <= 256 == blockDim
+  const int i = static_cast<int>(threadIdx.x);
+  if (i < total) {
+    const uint64_t mine = sh[i];
+    int rank = 0;
+    for (int j = 0; j < total; ++j) {
+      const uint64_t o = sh[j];
+      rank += (o > mine || (o == mine && j < i)) ? 1 : 0;
+    }
+    if (rank < c) dst[rank] = mine;
+  }
+}
+
 template <int SPACE>
 __device__ __forceinline__ float accum4(f32x4 e, f32x4 q, float acc) {
   if constexpr (SPACE == DEWI_SPACE_COSINE) {
@@ -96,12 +119,16 @@ __device__ __forceinline__ float accum4(f32x4 e, f32x4 q, float acc) {
 // ---------------------------------------------------------------------------------------------
 // Fast path: dim == 256*U, one row per wavefront step, R rows per iteration, NQ queries per pass.
 // ---------------------------------------------------------------------------------------------
-template <int U, int R, int NQ, int SPACE, bool DENSE, bool NT>
+// S = key slots per lane: 1 (c <= 64, block-merged sorted output, one list per workgroup),
+// 4 (c <= 256, one unsorted list per wave) or 0 (dense: one key per row).
+template <int U, int R, int NQ, int SPACE, int S, bool NT>
 __global__ __launch_bounds__(kScanThreads) void scan_rows_f32(const float* __restrict__ E, int64_t n_rows,
                                                               const float* __restrict__ Q, int n_candidates,
                                                               uint64_t* __restrict__ keys,
                                                               int64_t keys_per_query) {
   constexpr int D4 = 64 * U;  // float4 units per row
+  constexpr bool DENSE = S == 0;
+  __shared__ uint64_t merge_buf[S == 1 ? kScanThreads : 1];
   const int lane = lane_id();
   const int wave_in_block = static_cast<int>(threadIdx.x) >> 6;
   const int64_t gwave = static_cast<int64_t>(blockIdx.x) * (kScanThreads / kWave) + wave_in_block;
@@ -138,7 +165,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_rows_f32(const float* __res
     }
   }
 
-  WaveList lst[DENSE ? 1 : NQ];
+  WaveList<DENSE ? 1 : S> lst[DENSE ? 1 : NQ];
   if constexpr (!DENSE) {
 #pragma unroll
     for (int qi = 0; qi < NQ; ++qi) lst[qi].init(n_candidates, lane);
@@ -184,7 +211,12 @@ __global__ __launch_bounds__(kScanThreads) void scan_rows_f32(const float* __res
     consume(v, row);
   }
 
-  if constexpr (!DENSE) {
+  if constexpr (S == 1) {
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi)
+      block_merge_store(lst[qi], merge_buf, keys + qi * keys_per_query + static_cast<int64_t>(blockIdx.x) * n_candidates,
+                        n_candidates, lane, wave_in_block);
+  } else if constexpr (!DENSE) {
 #pragma unroll
     for (int qi = 0; qi < NQ; ++qi)
       lst[qi].store(keys + qi * keys_per_query + gwave * n_candidates, n_candidates, lane);
@@ -203,12 +235,14 @@ struct VecT<1> { using type = float; };
 template <>
 struct VecT<4> { using type = f32x4; };
 
-template <int VEC, int NQ, int SPACE, bool DENSE>
+template <int VEC, int NQ, int SPACE, int S>
 __global__ __launch_bounds__(kScanThreads) void scan_generic_f32(const float* __restrict__ E, int64_t n_rows, int dim,
                                                                  const float* __restrict__ Qn, int group,
                                                                  int n_candidates, uint64_t* __restrict__ keys,
                                                                  int64_t keys_per_query) {
   using V = typename VecT<VEC>::type;
+  constexpr bool DENSE = S == 0;
+  __shared__ uint64_t merge_buf[S == 1 ? kScanThreads : 1];
   const int lane = lane_id();
   const int wave_in_block = static_cast<int>(threadIdx.x) >> 6;
   const int64_t gwave = static_cast<int64_t>(blockIdx.x) * (kScanThreads / kWave) + wave_in_block;
@@ -218,7 +252,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_generic_f32(const float* __
   const int lg = lane % group;   // position inside the row group
   const int units = dim / VEC;
 
-  WaveList lst[DENSE ? 1 : NQ];
+  WaveList<DENSE ? 1 : S> lst[DENSE ? 1 : NQ];
   if constexpr (!DENSE) {
 #pragma unroll
     for (int qi = 0; qi < NQ; ++qi) lst[qi].init(n_candidates, lane);
@@ -270,7 +304,12 @@ __global__ __launch_bounds__(kScanThreads) void scan_generic_f32(const float* __
       }
     }
   }
-  if constexpr (!DENSE) {
+  if constexpr (S == 1) {
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi)
+      block_merge_store(lst[qi], merge_buf, keys + qi * keys_per_query + static_cast<int64_t>(blockIdx.x) * n_candidates,
+                        n_candidates, lane, wave_in_block);
+  } else if constexpr (!DENSE) {
 #pragma unroll
     for (int qi = 0; qi < NQ; ++qi)
       lst[qi].store(keys + qi * keys_per_query + gwave * n_candidates, n_candidates, lane);
@@ -335,67 +374,69 @@ ScanPlan plan_scan(int64_t n_rows, int dim, int elem_bytes, int n_candidates, in
   p.blocks = static_cast<int>(blocks);
   p.waves = p.blocks * (kScanThreads / kWave);
   p.nq_per_launch = 4;
-  p.keys_per_query = p.dense ? n_rows : static_cast<int64_t>(p.waves) * n_candidates;
+  p.slots = p.dense ? 0 : (n_candidates <= kWave ? 1 : kMaxSlots);
+  p.n_lists = p.dense ? 0 : (p.slots == 1 ? p.blocks : p.waves);
+  p.keys_per_query = p.dense ? n_rows : static_cast<int64_t>(p.n_lists) * n_candidates;
   return p;
 }
 
-template <int U, int R, int NQ, int SPACE, bool DENSE>
+template <int U, int R, int NQ, int SPACE, int S>
 static void launch_fast_nt(const ScanPlan& plan, const float* E, int64_t n_rows, const float* Q, int c,
                            uint64_t* keys, hipStream_t stream) {
   if (plan.nontemporal)
-    hipLaunchKernelGGL((scan_rows_f32<U, R, NQ, SPACE, DENSE, true>), dim3(plan.blocks), dim3(kScanThreads), 0,
+    hipLaunchKernelGGL((scan_rows_f32<U, R, NQ, SPACE, S, true>), dim3(plan.blocks), dim3(kScanThreads), 0,
                        stream, E, n_rows, Q, c, keys, plan.keys_per_query);
   else
-    hipLaunchKernelGGL((scan_rows_f32<U, R, NQ, SPACE, DENSE, false>), dim3(plan.blocks), dim3(kScanThreads), 0,
+    hipLaunchKernelGGL((scan_rows_f32<U, R, NQ, SPACE, S, false>), dim3(plan.blocks), dim3(kScanThreads), 0,
                        stream, E, n_rows, Q, c, keys, plan.keys_per_query);
 }
 
-template <int U, int NQ, int SPACE, bool DENSE>
+template <int U, int NQ, int SPACE, int S>
 static bool launch_fast_r(const ScanPlan& plan, const float* E, int64_t n_rows, const float* Q, int c,
                           uint64_t* keys, hipStream_t stream) {
   switch (plan.rows_per_iter) {
-    case 2: launch_fast_nt<U, 2, NQ, SPACE, DENSE>(plan, E, n_rows, Q, c, keys, stream); return true;
+    case 2: launch_fast_nt<U, 2, NQ, SPACE, S>(plan, E, n_rows, Q, c, keys, stream); return true;
     case 4:
-      if constexpr (U <= 3) { launch_fast_nt<U, 4, NQ, SPACE, DENSE>(plan, E, n_rows, Q, c, keys, stream); return true; }
+      if constexpr (U <= 3) { launch_fast_nt<U, 4, NQ, SPACE, S>(plan, E, n_rows, Q, c, keys, stream); return true; }
       return false;
     case 8:
-      if constexpr (U <= 3 && NQ == 1 && !DENSE) { launch_fast_nt<U, 8, NQ, SPACE, DENSE>(plan, E, n_rows, Q, c, keys, stream); return true; }
+      if constexpr (U <= 3 && NQ == 1 && S == 1) { launch_fast_nt<U, 8, NQ, SPACE, S>(plan, E, n_rows, Q, c, keys, stream); return true; }
       return false;
     default: return false;
   }
 }
 
-template <int NQ, int SPACE, bool DENSE>
+template <int NQ, int SPACE, int S>
 static bool launch_fast_u(const ScanPlan& plan, int dim, const float* E, int64_t n_rows, const float* Q, int c,
                           uint64_t* keys, hipStream_t stream) {
   switch (dim / 256) {
-    case 1: return launch_fast_r<1, NQ, SPACE, DENSE>(plan, E, n_rows, Q, c, keys, stream);
-    case 2: return launch_fast_r<2, NQ, SPACE, DENSE>(plan, E, n_rows, Q, c, keys, stream);
-    case 3: return launch_fast_r<3, NQ, SPACE, DENSE>(plan, E, n_rows, Q, c, keys, stream);
-    case 4: return launch_fast_r<4, NQ, SPACE, DENSE>(plan, E, n_rows, Q, c, keys, stream);
-    case 6: return launch_fast_r<6, NQ, SPACE, DENSE>(plan, E, n_rows, Q, c, keys, stream);
+    case 1: return launch_fast_r<1, NQ, SPACE, S>(plan, E, n_rows, Q, c, keys, stream);
+    case 2: return launch_fast_r<2, NQ, SPACE, S>(plan, E, n_rows, Q, c, keys, stream);
+    case 3: return launch_fast_r<3, NQ, SPACE, S>(plan, E, n_rows, Q, c, keys, stream);
+    case 4: return launch_fast_r<4, NQ, SPACE, S>(plan, E, n_rows, Q, c, keys, stream);
+    case 6: return launch_fast_r<6, NQ, SPACE, S>(plan, E, n_rows, Q, c, keys, stream);
     default: return false;
   }
 }
 
-template <int NQ, int SPACE, bool DENSE>
+template <int NQ, int SPACE, int S>
 static void launch_generic(const ScanPlan& plan, int dim, const float* E, int64_t n_rows, const float* Qn, int c,
                            uint64_t* keys, hipStream_t stream) {
   if (plan.vec == 4)
-    hipLaunchKernelGGL((scan_generic_f32<4, NQ, SPACE, DENSE>), dim3(plan.blocks), dim3(kScanThreads), 0, stream, E,
+    hipLaunchKernelGGL((scan_generic_f32<4, NQ, SPACE, S>), dim3(plan.blocks), dim3(kScanThreads), 0, stream, E,
                        n_rows, dim, Qn, plan.group, c, keys, plan.keys_per_query);
   else
-    hipLaunchKernelGGL((scan_generic_f32<1, NQ, SPACE, DENSE>), dim3(plan.blocks), dim3(kScanThreads), 0, stream, E,
+    hipLaunchKernelGGL((scan_generic_f32<1, NQ, SPACE, S>), dim3(plan.blocks), dim3(kScanThreads), 0, stream, E,
                        n_rows, dim, Qn, plan.group, c, keys, plan.keys_per_query);
 }
 
-template <int NQ, int SPACE, bool DENSE>
+template <int NQ, int SPACE, int S>
 static hipError_t launch_scan_impl(const ScanPlan& plan, const float* E, int64_t n_rows, int dim, const float* Qraw,
                                    const float* Qn, int c, uint64_t* keys, hipStream_t stream) {
   if (plan.fast) {
-    if (!launch_fast_u<NQ, SPACE, DENSE>(plan, dim, E, n_rows, Qraw, c, keys, stream)) return hipErrorInvalidValue;
+    if (!launch_fast_u<NQ, SPACE, S>(plan, dim, E, n_rows, Qraw, c, keys, stream)) return hipErrorInvalidValue;
   } else {
-    launch_generic<NQ, SPACE, DENSE>(plan, dim, E, n_rows, Qn, c, keys, stream);
+    launch_generic<NQ, SPACE, S>(plan, dim, E, n_rows, Qn, c, keys, stream);
   }
   return hipGetLastError();
 }
@@ -406,19 +447,25 @@ hipError_t launch_scan_f32(const ScanPlan& plan, const float* d_E, int64_t n_row
   const float* qr = d_q_raw + static_cast<int64_t>(q0) * dim;
   const float* qn = d_q_norm ? d_q_norm + static_cast<int64_t>(q0) * dim : nullptr;
   uint64_t* keys = d_keys + static_cast<int64_t>(q0) * plan.keys_per_query;
-#define DEWI_DISPATCH(NQ)                                                                                            \
-  if (space == DEWI_SPACE_COSINE)                                                                                    \
-    return plan.dense ? launch_scan_impl<NQ, DEWI_SPACE_COSINE, true>(plan, d_E, n_rows, dim, qr, qn, n_candidates, keys, stream)  \
-                      : launch_scan_impl<NQ, DEWI_SPACE_COSINE, false>(plan, d_E, n_rows, dim, qr, qn, n_candidates, keys, stream); \
-  else                                                                                                               \
-    return plan.dense ? launch_scan_impl<NQ, DEWI_SPACE_L2, true>(plan, d_E, n_rows, dim, qr, qn, n_candidates, keys, stream)      \
-                      : launch_scan_impl<NQ, DEWI_SPACE_L2, false>(plan, d_E, n_rows, dim, qr, qn, n_candidates, keys, stream);
+#define DEWI_DISPATCH_S(NQ, SPACE)                                                                              \
+  switch (plan.slots) {                                                                                          \
+    case 0: return launch_scan_impl<NQ, SPACE, 0>(plan, d_E, n_rows, dim, qr, qn, n_candidates, keys, stream);   \
+    case 1: return launch_scan_impl<NQ, SPACE, 1>(plan, d_E, n_rows, dim, qr, qn, n_candidates, keys, stream);   \
+    default: return launch_scan_impl<NQ, SPACE, kMaxSlots>(plan, d_E, n_rows, dim, qr, qn, n_candidates, keys, stream); \
+  }
+#define DEWI_DISPATCH(NQ)                                  \
+  if (space == DEWI_SPACE_COSINE) {                        \
+    DEWI_DISPATCH_S(NQ, DEWI_SPACE_COSINE)                 \
+  } else {                                                 \
+    DEWI_DISPATCH_S(NQ, DEWI_SPACE_L2)                     \
+  }
   if (nq == 1) {
     DEWI_DISPATCH(1)
   } else if (nq == 4) {
     DEWI_DISPATCH(4)
   }
 #undef DEWI_DISPATCH
+#undef DEWI_DISPATCH_S
   return hipErrorInvalidValue;
 }
 

@@ -22,6 +22,9 @@ struct ScanPlan {
   int rows_per_iter;  // rows each wave loads before it reduces (fast path)
   bool fast;          // dim == 256*U fp32 (U = 1..6), 16-byte aligned rows: row-per-wave kernel
   bool dense;         // one key per row instead of per-wave lists
+  int slots;          // key registers per lane per query: 1 (c <= 64), 4 (c <= 256), 0 (dense)
+  int n_lists;        // candidate lists the scan emits per query: workgroups (slots == 1, each sorted
+                      // descending) or wavefronts (slots == 4, unsorted); 0 when dense
   int group;          // generic path: lanes per row (power of two, <= 64)
   int vec;            // generic path: 4 if rows can be read as float4, else 1
   int nq_per_launch;  // queries handled by one corpus pass
@@ -57,8 +60,9 @@ struct RerankParams {
 };
 // keys [n_queries][keys_per_query] -> top n_candidates by key -> either final (ids, scores) or
 // sorted candidate records.
-hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, int n_queries, int n_candidates,
-                                int k, const RerankParams& rp, const float* d_dewi32, const float* d_ent32,
+// sorted_lists > 0: the keys are `sorted_lists` lists of n_candidates keys, each sorted descending.
+hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, int sorted_lists, int n_queries,
+                                int n_candidates, int k, const RerankParams& rp, const float* d_dewi32, const float* d_ent32,
                                 int64_t id_offset, int64_t* d_out_ids, float* d_out_scores,
                                 dewi_candidate* d_out_cand, hipStream_t stream);
 hipError_t launch_merge_rerank(const dewi_candidate* d_lists, int n_lists, int n_queries, int list_len,

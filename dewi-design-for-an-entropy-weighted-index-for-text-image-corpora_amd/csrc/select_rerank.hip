@@ -51,7 +51,7 @@ __device__ void bitonic_sort_desc(uint64_t* key, uint32_t* val, int p2) {
 // Threshold T such that exactly `kth` of the non-empty keys are >= T (keys are unique).  If fewer
 // than `kth` non-empty keys exist, returns 1 (every non-empty key).  All threads return the same
 // value.  MSB-first radix select, 8 bits per pass, early exit once a whole bin is taken.
-__device__ uint64_t block_kth_largest(const uint64_t* __restrict__ keys, int64_t m, uint32_t kth, SelectShared& sh) {
+__device__ uint64_t block_kth_largest(const uint64_t* keys, int64_t m, uint32_t kth, SelectShared& sh) {
   const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
   const int lane = tid & 63, wave = tid >> 6;
   uint64_t prefix = 0;
@@ -146,15 +146,45 @@ __device__ void rerank_and_emit(SelectShared& sh, int n_sel, int k, const Rerank
 // ---------------------------------------------------------------------------------------------
 // Single-device (or per-shard) select: keys from the scan -> final results or candidate records.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(
-    const uint64_t* __restrict__ keys_all, int64_t keys_per_query, int n_candidates, int k, RerankParams rp,
-    const float* __restrict__ dewi32, const float* __restrict__ ent32, int64_t id_offset,
-    int64_t* __restrict__ out_ids, float* __restrict__ out_scores, dewi_candidate* __restrict__ out_cand) {
-  __shared__ SelectShared sh;
+// Gathers the best n_candidates keys of one query into sh.sel, sorted descending; returns how many
+// are valid.  Two routes:
+//  * sorted lists (the scan's block-merged output: n_lists lists of n_candidates keys, each sorted
+//    descending): the c-th largest LIST MAXIMUM is a lower bound of the c-th largest key overall
+//    (the c largest maxima are c distinct keys), so only keys >= that bound can matter.  Each
+//    thread walks one list from the top and stops at the first key below the bound: ~1-2 reads per
+//    list instead of c, and typically c..2c survivors that a small bitonic sort finishes.
+//  * anything else: exact 8-bit MSB radix select over all keys, then compaction and sort.
+__device__ int gather_top_candidates(const uint64_t* __restrict__ keys, int64_t keys_per_query, int sorted_lists,
+                                     int n_candidates, SelectShared& sh) {
   const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
-  const int q = static_cast<int>(blockIdx.x);
-  const uint64_t* keys = keys_all + static_cast<int64_t>(q) * keys_per_query;
-
+  if (sorted_lists > 0 && sorted_lists <= kMaxSortCandidates) {
+    uint64_t bound = 1ull;  // every non-empty key
+    if (sorted_lists >= n_candidates) {
+      for (int t = tid; t < sorted_lists; t += nt) sh.sel2[t] = keys[static_cast<int64_t>(t) * n_candidates];
+      __syncthreads();
+      bound = block_kth_largest(sh.sel2, sorted_lists, static_cast<uint32_t>(n_candidates), sh);
+    }
+    if (tid == 0) sh.count = 0;
+    __syncthreads();
+    for (int t = tid; t < sorted_lists; t += nt) {
+      const uint64_t* lst = keys + static_cast<int64_t>(t) * n_candidates;
+      for (int j = 0; j < n_candidates; ++j) {
+        const uint64_t key = lst[j];
+        if (key == kKeyEmpty || key < bound) break;
+        const uint32_t pos = atomicAdd(&sh.count, 1u);
+        if (pos < static_cast<uint32_t>(kMaxSortCandidates)) sh.sel[pos] = key;
+      }
+    }
+    __syncthreads();
+    const uint32_t survivors = sh.count;
+    if (survivors <= static_cast<uint32_t>(kMaxSortCandidates)) {
+      const int p2 = pow2_at_least(static_cast<int>(survivors));
+      for (int t = static_cast<int>(survivors) + tid; t < p2; t += nt) sh.sel[t] = kKeyEmpty;
+      bitonic_sort_desc<false>(sh.sel, nullptr, p2);
+      return static_cast<int>(survivors < static_cast<uint32_t>(n_candidates) ? survivors : n_candidates);
+    }
+    __syncthreads();  // too many survivors for LDS (degenerate input): exact select below
+  }
   const uint64_t thr = block_kth_largest(keys, keys_per_query, static_cast<uint32_t>(n_candidates), sh);
   if (tid == 0) sh.count = 0;
   const int p2 = pow2_at_least(n_candidates);
@@ -170,6 +200,18 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(
   __syncthreads();
   const int n_sel = static_cast<int>(sh.count < static_cast<uint32_t>(n_candidates) ? sh.count : n_candidates);
   bitonic_sort_desc<false>(sh.sel, nullptr, p2);
+  return n_sel;
+}
+
+__global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(
+    const uint64_t* __restrict__ keys_all, int64_t keys_per_query, int sorted_lists, int n_candidates, int k,
+    RerankParams rp, const float* __restrict__ dewi32, const float* __restrict__ ent32, int64_t id_offset,
+    int64_t* __restrict__ out_ids, float* __restrict__ out_scores, dewi_candidate* __restrict__ out_cand) {
+  __shared__ SelectShared sh;
+  const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
+  const int q = static_cast<int>(blockIdx.x);
+  const uint64_t* keys = keys_all + static_cast<int64_t>(q) * keys_per_query;
+  const int n_sel = gather_top_candidates(keys, keys_per_query, sorted_lists, n_candidates, sh);
 
   if (out_cand != nullptr) {
     dewi_candidate* oc = out_cand + static_cast<int64_t>(q) * n_candidates;
@@ -246,13 +288,15 @@ __global__ __launch_bounds__(kSelectThreads) void merge_rerank_kernel(const dewi
                   out_scores + static_cast<int64_t>(q) * k);
 }
 
-hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, int n_queries, int n_candidates,
-                                int k, const RerankParams& rp, const float* d_dewi32, const float* d_ent32,
-                                int64_t id_offset, int64_t* d_out_ids, float* d_out_scores,
+hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, int sorted_lists, int n_queries,
+                                int n_candidates, int k, const RerankParams& rp, const float* d_dewi32,
+                                const float* d_ent32, int64_t id_offset, int64_t* d_out_ids, float* d_out_scores,
                                 dewi_candidate* d_out_cand, hipStream_t stream) {
-  const int threads = keys_per_query <= 4096 && n_candidates <= 128 ? 256 : kSelectThreads;
+  int threads = kSelectThreads;
+  if (sorted_lists > 0 ? sorted_lists <= 256 : (keys_per_query <= 4096 && n_candidates <= 128)) threads = 256;
   hipLaunchKernelGGL(select_rerank_kernel, dim3(n_queries), dim3(threads), 0, stream, d_keys, keys_per_query,
-                     n_candidates, k, rp, d_dewi32, d_ent32, id_offset, d_out_ids, d_out_scores, d_out_cand);
+                     sorted_lists, n_candidates, k, rp, d_dewi32, d_ent32, id_offset, d_out_ids, d_out_scores,
+                     d_out_cand);
   return hipGetLastError();
 }
 
