@@ -77,8 +77,8 @@ struct WaveList {
   }
 };
 
-// Block-level merge of the four per-wave lists (single-slot lists, c <= 64): every wave drops its
-// c keys into LDS, each thread ranks one key against all 4c (broadcast reads), and the c best
+// Block-level merge of the per-wave lists (single-slot lists, c <= 64): every wave drops its
+// c keys into LDS, each thread ranks one key against all of them (broadcast reads), and the c best
 // leave the kernel already sorted descending.  Empty keys tie at 0 and are ordered by position.
 __device__ __forceinline__ void block_merge_store(const WaveList<1>& lst, uint64_t* __restrict__ sh,
                                                   uint64_t* __restrict__ dst, int c, int lane, int wave_in_block) {
@@ -86,7 +86,7 @@ __device__ __forceinline__ void block_merge_store(const WaveList<1>& lst, uint64
   __syncthreads();  // sh may still be read by the previous query's merge
   if (lane < c) sh[wave_in_block * c + lane] = lst.key[0];
   __syncthreads();
-  const int total = kWavesPerBlock * c;  // <= 256 == blockDim
+  const int total = kWavesPerBlock * c;  // <= blockDim because c <= 64
   const int i = static_cast<int>(threadIdx.x);
   if (i < total) {
     const uint64_t mine = sh[i];
@@ -188,7 +188,10 @@ __global__ __launch_bounds__(kScanThreads) void scan_rows_f32(const float* __res
     }
   };
 
-  // Full R-row groups.
+  // Full R-row groups.  Deliberately NOT software-pipelined and with a small R: on MI355X the scan
+  // is fastest with only ~24 KiB of loads in flight per CU (8 waves x one 3 KiB row; 1M x 768:
+  // R=1 0.434 ms, R=2 0.449, R=8 0.459, prefetching the next group 0.441) — more outstanding
+  // requests lower the achieved HBM rate instead of raising it.
   const int64_t n_groups = n_rows / R;
   for (int64_t g = gwave; g < n_groups; g += n_waves) {
     const int64_t row0 = g * R;
@@ -359,12 +362,14 @@ ScanPlan plan_scan(int64_t n_rows, int dim, int elem_bytes, int n_candidates, in
   p.dense = n_candidates > kMaxListCandidates;
   p.vec = (dim % 4 == 0) ? 4 : 1;
   p.group = p.fast ? kWave : (next_pow2((dim + p.vec - 1) / p.vec) > kWave ? kWave : next_pow2((dim + p.vec - 1) / p.vec));
-  p.rows_per_iter = p.fast ? (u <= 3 ? 4 : 2) : kWave / p.group;
+  p.rows_per_iter = p.fast ? (u == 1 ? 4 : (u == 2 ? 2 : 1)) : kWave / p.group;  // ~3-4 KiB in flight per wave
   if (p.fast && tuning.rows_per_iter > 0) p.rows_per_iter = tuning.rows_per_iter;
   p.nontemporal = tuning.nontemporal < 0 ? true : tuning.nontemporal != 0;
-  // Enough workgroups to fill every CU several times over, but never more waves than there are
-  // row groups to give each wave at least four iterations of work.
-  int64_t max_blocks = static_cast<int64_t>(compute_units) * 8;
+  // One 8-wave workgroup per CU (8 waves x R*U KiB in flight each): 8 waves per CU measured
+  // fastest on MI355X (1M x 768, R=8: 0.443 ms vs 0.448 ms at 32 waves per CU with R=4), and one
+  // list per CU keeps the select kernel's input at compute_units lists.  Never more waves than
+  // there are row groups to give each wave at least four iterations of work.
+  int64_t max_blocks = static_cast<int64_t>(compute_units);
   if (tuning.scan_blocks > 0) max_blocks = tuning.scan_blocks;
   const int64_t rows_per_wave_iter = p.rows_per_iter;
   const int64_t groups = (n_rows + rows_per_wave_iter - 1) / rows_per_wave_iter;
@@ -394,16 +399,29 @@ static void launch_fast_nt(const ScanPlan& plan, const float* E, int64_t n_rows,
 template <int U, int NQ, int SPACE, int S>
 static bool launch_fast_r(const ScanPlan& plan, const float* E, int64_t n_rows, const float* Q, int c,
                           uint64_t* keys, hipStream_t stream) {
-  switch (plan.rows_per_iter) {
-    case 2: launch_fast_nt<U, 2, NQ, SPACE, S>(plan, E, n_rows, Q, c, keys, stream); return true;
-    case 4:
-      if constexpr (U <= 3) { launch_fast_nt<U, 4, NQ, SPACE, S>(plan, E, n_rows, Q, c, keys, stream); return true; }
-      return false;
-    case 8:
-      if constexpr (U <= 3 && NQ == 1 && S == 1) { launch_fast_nt<U, 8, NQ, SPACE, S>(plan, E, n_rows, Q, c, keys, stream); return true; }
-      return false;
-    default: return false;
+  // R only changes how rows are grouped per wave; results do not depend on it.  Combinations that
+  // are not instantiated (register budget, build time) step down to the next smaller R.
+  const int r = plan.rows_per_iter;
+  if (r >= 8) {
+    if constexpr (U <= 3 && NQ == 1 && S == 1) {
+      launch_fast_nt<U, 8, NQ, SPACE, S>(plan, E, n_rows, Q, c, keys, stream);
+      return true;
+    }
   }
+  if (r >= 4) {
+    if constexpr (U <= 3 && NQ == 1) {
+      launch_fast_nt<U, 4, NQ, SPACE, S>(plan, E, n_rows, Q, c, keys, stream);
+      return true;
+    }
+  }
+  if (r >= 2) {
+    if constexpr (U <= 3) {
+      launch_fast_nt<U, 2, NQ, SPACE, S>(plan, E, n_rows, Q, c, keys, stream);
+      return true;
+    }
+  }
+  launch_fast_nt<U, 1, NQ, SPACE, S>(plan, E, n_rows, Q, c, keys, stream);
+  return true;
 }
 
 template <int NQ, int SPACE, int S>

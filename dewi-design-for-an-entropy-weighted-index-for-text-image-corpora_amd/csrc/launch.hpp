@@ -13,12 +13,15 @@ namespace dewi {
 constexpr int kMaxListCandidates = 256;
 // The select / re-rank kernel sorts its candidates in LDS.
 constexpr int kMaxSortCandidates = 2048;
-constexpr int kScanThreads = 256;   // 4 waves per workgroup
+#ifndef DEWI_SCAN_THREADS
+#define DEWI_SCAN_THREADS 512
+#endif
+constexpr int kScanThreads = DEWI_SCAN_THREADS;   // 8 waves per workgroup (256 only for tuning experiments)
 constexpr int kSelectThreads = 1024;
 
 struct ScanPlan {
   int blocks;         // workgroups of kScanThreads
-  int waves;          // blocks * 4
+  int waves;          // blocks * (kScanThreads / 64)
   int rows_per_iter;  // rows each wave loads before it reduces (fast path)
   bool fast;          // dim == 256*U fp32 (U = 1..6), 16-byte aligned rows: row-per-wave kernel
   bool dense;         // one key per row instead of per-wave lists

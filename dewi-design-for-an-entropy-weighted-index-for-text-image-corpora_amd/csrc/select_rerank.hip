@@ -48,6 +48,25 @@ __device__ void bitonic_sort_desc(uint64_t* key, uint32_t* val, int p2) {
   __syncthreads();
 }
 
+// Descending sort by ranking: thread t counts the keys that beat src[t] (broadcast LDS reads) and
+// drops it at that position of dst.  O(n^2 / threads) work but a single barrier, which beats the
+// log^2(n) barriers of the bitonic network for the few dozen keys the usual query ends with.
+// Equal keys (only the empty key can repeat) are ordered by position.  src != dst.
+constexpr int kRankSortMax = 256;
+__device__ void rank_sort_desc(const uint64_t* src, uint64_t* dst, int n) {
+  const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
+  for (int t = tid; t < n; t += nt) {
+    const uint64_t mine = src[t];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      const uint64_t o = src[j];
+      rank += (o > mine || (o == mine && j < t)) ? 1 : 0;
+    }
+    dst[rank] = mine;
+  }
+  __syncthreads();
+}
+
 // Threshold T such that exactly `kth` of the non-empty keys are >= T (keys are unique).  If fewer
 // than `kth` non-empty keys exist, returns 1 (every non-empty key).  All threads return the same
 // value.  MSB-first radix select, 8 bits per pass, early exit once a whole bin is taken.
@@ -131,6 +150,23 @@ __device__ void rerank_and_emit(SelectShared& sh, int n_sel, int k, const Rerank
     }
     sh.sel2[t] = k2;
   }
+  if (n_sel <= kRankSortMax) {
+    // few candidates: each thread ranks its own adjusted key and writes its output slot directly
+    __syncthreads();
+    for (int t = tid; t < n_sel; t += nt) {
+      const uint64_t mine = sh.sel2[t];
+      int rank = 0;
+      for (int j = 0; j < n_sel; ++j) rank += sh.sel2[j] > mine ? 1 : 0;  // adjusted keys are unique (low word = t)
+      if (rank < k) {
+        float dewi, ent;
+        int64_t id;
+        fetch(t, dewi, ent, id);
+        out_ids[rank] = id;
+        out_scores[rank] = unord_f32(static_cast<uint32_t>(mine >> 32));
+      }
+    }
+    return;
+  }
   bitonic_sort_desc<false>(sh.sel2, nullptr, p2);
   for (int j = tid; j < k && j < n_sel; j += nt) {
     const uint64_t k2 = sh.sel2[j];
@@ -148,42 +184,77 @@ __device__ void rerank_and_emit(SelectShared& sh, int n_sel, int k, const Rerank
 // ---------------------------------------------------------------------------------------------
 // Gathers the best n_candidates keys of one query into sh.sel, sorted descending; returns how many
 // are valid.  Two routes:
-//  * sorted lists (the scan's block-merged output: n_lists lists of n_candidates keys, each sorted
-//    descending): the c-th largest LIST MAXIMUM is a lower bound of the c-th largest key overall
-//    (the c largest maxima are c distinct keys), so only keys >= that bound can matter.  Each
-//    thread walks one list from the top and stops at the first key below the bound: ~1-2 reads per
-//    list instead of c, and typically c..2c survivors that a small bitonic sort finishes.
-//  * anything else: exact 8-bit MSB radix select over all keys, then compaction and sort.
+//  * sorted lists (the scan's block-merged output: `sorted_lists` lists of n_candidates keys, each
+//    sorted descending): the c-th largest LIST MAXIMUM is a lower bound of the c-th largest key
+//    overall (the c largest maxima are c distinct keys), and only the c lists with the largest
+//    maxima can hold a key at or above it.  So: rank the maxima (one barrier), let the owners of
+//    those c lists walk them from the top until they drop below the bound (~1-2 reads each), and
+//    rank-sort the c..2c survivors (one barrier).
+//  * anything else: exact 8-bit MSB radix select over all keys, then compaction and bitonic sort.
 __device__ int gather_top_candidates(const uint64_t* __restrict__ keys, int64_t keys_per_query, int sorted_lists,
                                      int n_candidates, SelectShared& sh) {
   const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
   if (sorted_lists > 0 && sorted_lists <= kMaxSortCandidates) {
-    uint64_t bound = 1ull;  // every non-empty key
-    if (sorted_lists >= n_candidates) {
-      for (int t = tid; t < sorted_lists; t += nt) sh.sel2[t] = keys[static_cast<int64_t>(t) * n_candidates];
-      __syncthreads();
-      bound = block_kth_largest(sh.sel2, sorted_lists, static_cast<uint32_t>(n_candidates), sh);
+    for (int t = tid; t < sorted_lists; t += nt) sh.sel2[t] = keys[static_cast<int64_t>(t) * n_candidates];
+    if (tid == 0) {
+      sh.count = 0;
+      sh.total = 0;       // "a list maximum ranked c-th" flag
+      sh.pick_digit = 0;  // index of that list
     }
-    if (tid == 0) sh.count = 0;
+    __syncthreads();
+    const bool all_lists = sorted_lists < n_candidates;
+    // rank of every maximum = number of maxima that beat it.  The L x L comparisons are split over
+    // all threads: `parts` threads share one list, each counting over a slice of the maxima.
+    for (int t = tid; t < sorted_lists; t += nt) sh.val[t] = 0;
+    __syncthreads();
+    const int parts = nt / sorted_lists > 1 ? nt / sorted_lists : 1;
+    const int slice = (sorted_lists + parts - 1) / parts;
+    for (int idx = tid; idx < sorted_lists * parts; idx += nt) {
+      const int t = idx / parts, part = idx % parts;
+      const uint64_t mine = sh.sel2[t];
+      const int j0 = part * slice, j1 = j0 + slice < sorted_lists ? j0 + slice : sorted_lists;
+      uint32_t cnt = 0;
+      for (int j = j0; j < j1; ++j) {
+        const uint64_t o = sh.sel2[j];
+        cnt += (o > mine || (o == mine && j < t)) ? 1u : 0u;
+      }
+      if (cnt) atomicAdd(&sh.val[t], cnt);
+    }
     __syncthreads();
     for (int t = tid; t < sorted_lists; t += nt) {
+      if (sh.val[t] == static_cast<uint32_t>(n_candidates - 1)) {
+        sh.pick_digit = static_cast<uint32_t>(t);
+        sh.total = 1;
+      }
+    }
+    __syncthreads();
+    uint64_t bound = 1ull;  // every non-empty key
+    if (!all_lists && sh.total != 0) bound = sh.sel2[sh.pick_digit];
+    if (bound == kKeyEmpty) bound = 1ull;
+    __syncthreads();        // maxima in sel2 are dead from here on; sel2 receives the survivors
+    for (int t = tid; t < sorted_lists; t += nt) {
+      if (!all_lists && sh.val[t] >= static_cast<uint32_t>(n_candidates)) continue;
       const uint64_t* lst = keys + static_cast<int64_t>(t) * n_candidates;
       for (int j = 0; j < n_candidates; ++j) {
         const uint64_t key = lst[j];
         if (key == kKeyEmpty || key < bound) break;
         const uint32_t pos = atomicAdd(&sh.count, 1u);
-        if (pos < static_cast<uint32_t>(kMaxSortCandidates)) sh.sel[pos] = key;
+        if (pos < static_cast<uint32_t>(kMaxSortCandidates)) sh.sel2[pos] = key;
       }
     }
     __syncthreads();
-    const uint32_t survivors = sh.count;
-    if (survivors <= static_cast<uint32_t>(kMaxSortCandidates)) {
-      const int p2 = pow2_at_least(static_cast<int>(survivors));
-      for (int t = static_cast<int>(survivors) + tid; t < p2; t += nt) sh.sel[t] = kKeyEmpty;
-      bitonic_sort_desc<false>(sh.sel, nullptr, p2);
-      return static_cast<int>(survivors < static_cast<uint32_t>(n_candidates) ? survivors : n_candidates);
+    const int survivors = static_cast<int>(sh.count);
+    if (survivors <= kRankSortMax) {
+      rank_sort_desc(sh.sel2, sh.sel, survivors);
+      return survivors < n_candidates ? survivors : n_candidates;
     }
-    __syncthreads();  // too many survivors for LDS (degenerate input): exact select below
+    if (survivors <= kMaxSortCandidates) {
+      const int p2 = pow2_at_least(survivors);
+      for (int t = tid; t < p2; t += nt) sh.sel[t] = t < survivors ? sh.sel2[t] : kKeyEmpty;
+      bitonic_sort_desc<false>(sh.sel, nullptr, p2);
+      return survivors < n_candidates ? survivors : n_candidates;
+    }
+    // more survivors than LDS holds (degenerate input): exact select below
   }
   const uint64_t thr = block_kth_largest(keys, keys_per_query, static_cast<uint32_t>(n_candidates), sh);
   if (tid == 0) sh.count = 0;
@@ -293,7 +364,11 @@ hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, 
                                 const float* d_ent32, int64_t id_offset, int64_t* d_out_ids, float* d_out_scores,
                                 dewi_candidate* d_out_cand, hipStream_t stream) {
   int threads = kSelectThreads;
-  if (sorted_lists > 0 ? sorted_lists <= 256 : (keys_per_query <= 4096 && n_candidates <= 128)) threads = 256;
+  if (sorted_lists > 0) {
+    threads = sorted_lists <= 64 ? 256 : kSelectThreads;
+  } else if (keys_per_query <= 4096 && n_candidates <= 128) {
+    threads = 256;
+  }
   hipLaunchKernelGGL(select_rerank_kernel, dim3(n_queries), dim3(threads), 0, stream, d_keys, keys_per_query,
                      sorted_lists, n_candidates, k, rp, d_dewi32, d_ent32, id_offset, d_out_ids, d_out_scores,
                      d_out_cand);
