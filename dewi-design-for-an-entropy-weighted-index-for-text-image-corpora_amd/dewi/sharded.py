@@ -1,0 +1,116 @@
+"""Doc-id sharded search across the GPUs of one node.
+
+The reference is single-process; this is the MI355X-native addition.  One process per GPU
+(``torch.distributed``; backend ``nccl`` is RCCL over xGMI).  Rank r owns the contiguous row range
+``[offset_r, offset_r + n_r)`` of the corpus plus the matching payload columns.  Per query batch:
+
+  1. every rank scans its shard and keeps its best ``c = min(2k, N_global)`` rows by similarity as
+     16-byte records (sim, dewi32, ent32, global id), sorted — ``dewi_knn_candidates``;
+  2. ONE all-gather of ``B x c`` records per rank (k=10, B=1: 320 B — latency-bound, so a single
+     small collective, not a reduction tree);
+  3. every rank selects the global top-c by (sim desc, id asc), applies the eta blend and takes the
+     top-k — ``dewi_merge_rerank`` — so all ranks hold the identical answer.
+
+The similarity cut is global and happens before the blend, exactly as in the single-device path,
+so the result is independent of the sharding.
+
+``scan_fn`` / ``merge_fn`` exist so that the exchange logic (shard arithmetic, record layout,
+gather order, padding of short shards) can be exercised on CPU-only hosts with ``gloo``; the
+defaults are the HIP kernels and there is no CPU implementation in this package.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+RECORD_WORDS = 4  # sim, dewi, ent (fp32 bit patterns) + id, as int32 words
+
+
+def shard_bounds(n_total: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous, balanced row ranges: shard r = [n*r//world, n*(r+1)//world)."""
+    return [((n_total * r) // world, (n_total * (r + 1)) // world) for r in range(world)]
+
+
+class ShardedSearcher:
+    """Search over a corpus sharded by doc id; one instance per rank."""
+
+    def __init__(self, local, n_local: int, group=None, scan_fn: Optional[Callable] = None,
+                 merge_fn: Optional[Callable] = None, device=None):
+        """``local``: this rank's ``DeviceCorpus`` (or any object, when ``scan_fn`` is given).
+
+        ``scan_fn(queries, c) -> int32 tensor [B, c, 4]`` of records sorted by (sim desc, id asc)
+        with ids already global and ``id = -1`` padding; ``merge_fn(lists[world, B, c, 4], c, k,
+        eta, entropy_pref) -> (ids int64 [B, k], scores fp32 [B, k])``.
+        """
+        import torch
+        import torch.distributed as dist
+        self._torch, self._dist = torch, dist
+        self.local = local
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
+        self.device = device if device is not None else getattr(local, "device", torch.device("cpu"))
+        # exclusive prefix sum of the shard sizes = id offsets; all ranks learn every size
+        sizes = [int(n_local)]
+        if self.world > 1:
+            gathered: List[Optional[int]] = [None] * self.world
+            dist.all_gather_object(gathered, int(n_local), group=group)
+            sizes = [int(s) for s in gathered]
+        self.sizes = sizes
+        self.n_total = int(sum(sizes))
+        self.id_offset = int(sum(sizes[: self.rank]))
+        have = getattr(local, "id_offset", self.id_offset)
+        if have != self.id_offset:
+            raise ValueError(f"rank {self.rank}: shard id_offset {have} != prefix sum of shard sizes {self.id_offset}")
+        if scan_fn is None:
+            scan_fn = lambda q, c: local.candidates_device(local.stage_queries(q), c)  # noqa: E731
+        if merge_fn is None:
+            from ._engine import merge_rerank_device
+            merge_fn = merge_rerank_device
+        self._scan, self._merge = scan_fn, merge_fn
+
+    def n_candidates(self, k: int) -> int:
+        return min(2 * int(k), self.n_total)          # reference backends.py:439, over the WHOLE corpus
+
+    # ------------------------------------------------------------------ exchange
+    def exchange(self, recs):
+        """all-gather [B, c, 4] int32 records -> [world, B, c, 4] on every rank."""
+        torch, dist = self._torch, self._dist
+        if self.world == 1:
+            return recs.unsqueeze(0)
+        if self.backend == "nccl":
+            out = torch.empty((self.world,) + tuple(recs.shape), dtype=recs.dtype, device=recs.device)
+            dist.all_gather_into_tensor(out.view(-1), recs.contiguous().view(-1), group=self.group)
+            return out
+        # gloo (CPU rehearsal, or several ranks sharing one GPU): stage through host memory
+        host = recs.detach().cpu().contiguous()
+        parts = [torch.empty_like(host) for _ in range(self.world)]
+        dist.all_gather(parts, host, group=self.group)
+        return torch.stack(parts).to(recs.device)
+
+    # ------------------------------------------------------------------ search
+    def search(self, queries, k: int = 10, eta: float = 0.5, entropy_pref: float = 0.0):
+        """[B, dim] queries (same on every rank) -> (global ids int64 [B, k], scores fp32 [B, k])."""
+        k = int(k)
+        if k <= 0:
+            b = 1 if np.ndim(queries) == 1 else len(queries)
+            return np.empty((b, 0), np.int64), np.empty((b, 0), np.float32)
+        if k > self.n_total:
+            raise ValueError(f"kth(={self.n_total - k}) out of bounds ({self.n_total})")   # as NumPy in the reference
+        c = self.n_candidates(k)
+        recs = self._scan(queries, c)
+        lists = self.exchange(recs)
+        ids, scores = self._merge(lists, c, k, float(eta), float(entropy_pref))
+        to_np = lambda t: t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)  # noqa: E731
+        return to_np(ids), to_np(scores)
+
+
+def build_local_shard(rows: np.ndarray, dewi: Sequence[float], ht_mean: Sequence[float], hi_mean: Sequence[float],
+                      rank: int, world: int, space: str = "cosine", device: Optional[str] = None):
+    """Slice the full host arrays to this rank's range and put the slice on the GPU."""
+    from ._engine import DeviceCorpus
+    lo, hi = shard_bounds(len(rows), world)[rank]
+    return DeviceCorpus.from_host(rows[lo:hi], np.asarray(dewi)[lo:hi], np.asarray(ht_mean)[lo:hi],
+                                  np.asarray(hi_mean)[lo:hi], space, device=device, id_offset=lo)

@@ -1,0 +1,181 @@
+"""Multi-process tests of the doc-id sharded search.
+
+CPU (no GPU, gloo, world_size 2 and 3): the exchange logic of dewi/sharded.py — shard arithmetic,
+global candidate count, id offsets, [world, B, c, 4] gather layout, padding of short shards — with
+the CPU oracle plugged in as scan/merge.  GPU (`-m gpu`, two ranks sharing cuda:0, gloo staging):
+the real HIP kernels on both ranks against the single-device result.
+"""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = Path(__file__).resolve().parent.parent
+PKG = REPO / "dewi-design-for-an-entropy-weighted-index-for-text-image-corpora_amd"
+for p in (str(PKG), str(REPO / "oracle"), str(REPO / "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+N, D, B = 997, 32, 5            # ragged on purpose: 997 rows do not divide by 2 or 3
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _inputs():
+    import dewi_oracle as orc
+    raw = orc.synth_corpus(N, D, seed=123)
+    cols = orc.synth_payload_columns(N, seed=123)
+    Q = orc.synth_queries(B, D, seed=9)
+    return raw, cols, Q
+
+
+# ---- oracle-backed scan / merge used by the CPU rehearsal (test-side code) ---------------------
+def _pack(sim, dewi, ent, ids):
+    rec = np.zeros(sim.shape + (4,), np.int32)
+    rec[..., 0] = sim.astype(np.float32).view(np.int32)
+    rec[..., 1] = dewi.astype(np.float32).view(np.int32)
+    rec[..., 2] = ent.astype(np.float32).view(np.int32)
+    rec[..., 3] = ids.astype(np.int32)
+    return rec
+
+
+def _oracle_scan(E, lo, hi, dewi32, ent32, offset):
+    import dewi_oracle as orc
+
+    def scan(queries, c):
+        out = np.zeros((len(queries), c, 4), np.int32)
+        out[..., 0] = np.float32(-np.inf).view(np.int32)
+        out[..., 3] = -1
+        for b, q in enumerate(queries):
+            # BLAS rounds a row's dot product differently for different matrix shapes, so the shard's
+            # similarities are sliced from the whole-matrix product: same bits as the unsharded oracle
+            s = orc.similarities(E, orc.prepare_query(q))[lo:hi]
+            order = np.lexsort((np.arange(len(s)), -s.astype(np.float64)))[:c]     # sim desc, id asc
+            out[b, : len(order)] = _pack(s[order], dewi32[order], ent32[order], order + offset)
+        return torch.from_numpy(out)
+    return scan
+
+
+def _oracle_merge(lists, c, k, eta, pref):
+    import dewi_oracle as orc
+    a = lists.numpy()
+    world, b = a.shape[0], a.shape[1]
+    ids = np.zeros((b, k), np.int64)
+    sc = np.zeros((b, k), np.float32)
+    for q in range(b):
+        rec = a[:, q].reshape(-1, 4)
+        rec = rec[rec[:, 3] >= 0]
+        sim = rec[:, 0].copy().view(np.float32)
+        order = np.lexsort((rec[:, 3], -sim.astype(np.float64)))[:c]
+        rec, sim = rec[order], sim[order]
+        gid = rec[:, 3].astype(np.int64)
+        dewi = rec[:, 1].copy().view(np.float32)
+        ent = rec[:, 2].copy().view(np.float32)
+        # reuse the oracle's re-rank on a compact candidate set (indices 0..c-1)
+        loc, adj = orc.rerank(np.arange(len(gid)), sim, dewi, ent, k, eta, pref)
+        ids[q], sc[q] = gid[loc], adj
+    return torch.from_numpy(ids), torch.from_numpy(sc)
+
+
+def _cpu_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import dewi_oracle as orc
+        from dewi.sharded import ShardedSearcher, shard_bounds
+        raw, cols, Q = _inputs()
+        E = orc.build_matrix(raw)
+        dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+        lo, hi = shard_bounds(N, world)[rank]
+
+        class Local:
+            id_offset = lo
+            device = torch.device("cpu")
+        s = ShardedSearcher(Local(), hi - lo, scan_fn=_oracle_scan(E, lo, hi, dewi32[lo:hi], ent32[lo:hi], lo),
+                            merge_fn=_oracle_merge)
+        assert s.n_total == N and s.id_offset == lo and s.sizes == [b - a for a, b in shard_bounds(N, world)]
+        out = {}
+        for k, eta, pref in ((10, 0.3, 0.0), (3, 0.7, -0.4), (400, 0.25, 0.1)):   # k=400: c=800 > any shard
+            out[(k, eta, pref)] = s.search(Q, k, eta, pref)
+        with pytest.raises(ValueError, match="out of bounds"):
+            s.search(Q, N + 1, 0.3, 0.0)
+        assert s.search(Q, 0)[0].shape == (B, 0)
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_exchange_on_cpu_gloo(world):
+    import dewi_oracle as orc
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_cpu_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    raw, cols, Q = _inputs()
+    E = orc.build_matrix(raw)
+    dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    assert len(ret) == world
+    for key, (ids0, sc0) in ret[0].items():
+        k, eta, pref = key
+        for r in range(1, world):                                   # every rank holds the same answer
+            assert np.array_equal(ret[r][key][0], ids0) and np.array_equal(ret[r][key][1], sc0)
+        for b in range(B):                                          # and it is the unsharded answer
+            ids, sc = orc.search(E, Q[b], dewi32, ent32, k, eta, pref)
+            assert np.array_equal(ids0[b], ids), (key, b)
+            assert np.array_equal(sc0[b], sc), (key, b)
+
+
+def test_shard_bounds_cover_everything():
+    from dewi.sharded import shard_bounds
+    for n in (1, 7, 997, 1_000_000):
+        for w in (1, 2, 3, 8):
+            b = shard_bounds(n, w)
+            assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1
+
+
+# ---- GPU: two ranks share cuda:0, real kernels, gloo staging ------------------------------------
+def _gpu_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import dewi_oracle as orc
+        from dewi.sharded import ShardedSearcher, build_local_shard
+        torch.cuda.set_device(0)
+        n, d = 20_000, 768
+        raw = orc.synth_corpus(n, d, seed=31)
+        cols = orc.synth_payload_columns(n, seed=31)
+        Q = orc.synth_queries(6, d, seed=32)
+        local = build_local_shard(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"], rank, world)
+        s = ShardedSearcher(local, local.n_rows)
+        ret[rank] = {k: s.search(Q, k, 0.3, 0.2) for k in (10, 25)}
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_equal_single_device():
+    import dewi_oracle as orc
+    from dewi import _engine as eng
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_gpu_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    n, d = 20_000, 768
+    raw = orc.synth_corpus(n, d, seed=31)
+    cols = orc.synth_payload_columns(n, seed=31)
+    Q = orc.synth_queries(6, d, seed=32)
+    whole = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    for k in (10, 25):
+        ids, sc = whole.search(Q, k, 0.3, 0.2)
+        for r in (0, 1):
+            assert np.array_equal(ret[r][k][0], ids) and np.array_equal(ret[r][k][1], sc)
