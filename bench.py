@@ -103,15 +103,17 @@ def main():
     eng.tuning(args.scan_blocks, args.rows_per_iter, args.nontemporal)
 
     # ------------------------------------------------------------------ data, resident in HBM
+    full = full_cols = None
     if args.scaling == "strong":
         total_rows = args.docs
         lo = (total_rows * rank) // world
         hi = (total_rows * (rank + 1)) // world
         # every rank generates the same full stream and keeps its slice: identical to the 1-GPU corpus
-        full, cols = make_corpus(torch, total_rows, args.dim, 42, device)
+        full, full_cols = make_corpus(torch, total_rows, args.dim, 42, device)
         emb_raw = full[lo:hi].clone() if world > 1 else full
-        del full
-        cols = {k: v[lo:hi] for k, v in cols.items()}
+        cols = {k: v[lo:hi] for k, v in full_cols.items()}
+        if world == 1 or rank != 0 or args.scaling != "strong":
+            full = None      # rank 0 of a sharded run keeps the whole corpus for the post-run check
     else:
         total_rows = args.docs * world
         lo, hi = args.docs * rank, args.docs * (rank + 1)
@@ -146,30 +148,49 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=device)
     sharded = world > 1 or force_dist
-    if not sharded:
+    # Single GPU: queries back to back on ONE stream (scan, select; next query).  Overlapping the select
+    # of query i with the scan of query i+1 on a second stream (DEWI_BENCH_PIPELINE=1) was measured
+    # SLOWER on MI355X (0.4506 vs 0.4434 ms/step at 1M rows, 84.7 vs 77.3 us at 125K): the cross-stream
+    # event waits cost more than the 9 us select they hide.
+    serial = os.environ.get("DEWI_BENCH_PIPELINE", "0") != "1"
+    qs = [Q[j] for j in range(n_distinct)]
+    oi = [out_ids[j] for j in range(n_distinct)]
+    osc = [out_sc[j] for j in range(n_distinct)]
+    if not sharded and serial:
         def run(first, count):
             for i in range(first, first + count):
                 j = i % n_distinct
-                corpus.search_device(Q[j], k, eta, 0.0, out_ids[j], out_sc[j])
+                corpus.search_device(qs[j], k, eta, 0.0, oi[j], osc[j])
+    elif not sharded:
+        # Throughput loop: scans back to back on one stream; the select/blend/top-k of query i runs on
+        # a second stream and overlaps the scan of query i+1 (two workspaces in rotation).
+        pipe = eng.PipelinedSearcher(corpus, k, eta, 0.0, n_queries=B)
+
+        def run(first, count):
+            for i in range(first, first + count):
+                j = i % n_distinct
+                pipe.submit(qs[j], oi[j], osc[j])
+            pipe.drain()
     else:
-        # Software pipeline of depth `depth`: scan+select of query i, its all-gather (async, on RCCL's
-        # stream), and the merge of query i-depth+1 — so up to depth-1 all-gathers hide behind scans.
+        # Sharded throughput loop.  scan stream: scans back to back.  Current (finish) stream: candidate
+        # records of query i, its all-gather (async, RCCL's stream), and — `depth`-1 queries later — the
+        # merge.  Up to depth-1 all-gathers are in flight behind the scans.
         depth = 3
         nbuf = depth + 1
+        fin = torch.cuda.Stream()
+        torch.cuda.set_stream(fin)          # torch.distributed orders collectives against the current stream
+        pipe = eng.PipelinedSearcher(corpus, k, eta, 0.0, n_queries=B, n_candidates=c, finish_stream=fin)
         send = [torch.empty((B, c, 4), dtype=torch.int32, device=device) for _ in range(nbuf)]
         recv = [torch.empty((world, B, c, 4), dtype=torch.int32, device=device) for _ in range(nbuf)]
         send_flat = [t.view(-1) for t in send]
         recv_flat = [t.view(-1) for t in recv]
-        qs = [Q[j] for j in range(n_distinct)]
-        oi = [out_ids[j] for j in range(n_distinct)]
-        osc = [out_sc[j] for j in range(n_distinct)]
         from collections import deque
 
         def run(first, count):
             inflight = deque()
             for i in range(first, first + count):
                 j, s = i % n_distinct, i % nbuf
-                corpus.candidates_device(qs[j], c, send[s])
+                pipe.submit(qs[j], out_records=send[s])
                 work = dist.all_gather_into_tensor(recv_flat[s], send_flat[s], async_op=True)
                 inflight.append((work, j, s))
                 if len(inflight) >= depth:
@@ -180,6 +201,7 @@ def main():
                 pw, pj, ps = inflight.popleft()
                 pw.wait()
                 eng.merge_rerank_device(recv[ps], c, k, eta, 0.0, oi[pj], osc[pj])
+            pipe.drain()
 
     def barrier():
         if dist.is_initialized():
@@ -232,12 +254,38 @@ def main():
                                f"brute-force cosine kNN + DEWI re-rank (BASELINE.json configs[1])",
                    "docs": total_rows, "dim": args.dim, "k": k, "eta": eta, "batch": B, "candidates": c,
                    "parallelism": f"doc-id shards x{world} + RCCL all-gather" if sharded else "single GPU",
+                   "queries_in_flight": 1 if (serial and not sharded) else (3 if sharded else 2),
                    "rows_per_gpu": n_local},
         "roofline": {"bound": "hbm", "kernel": "scan_rows_f32", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": algo_bytes, "mean_kernel_ms": round(scan_ms, 5),
                      "launches_timed": scan_launches},
     }
+
+    # ------------------------------------------------------------------ sharded result == single-GPU result
+    if rank == 0 and sharded:
+        if world > 1:
+            nat.check(nat.load_library().dewi_normalize_rows_f32(nat.ptr(full), nat.ptr(full), total_rows, args.dim,
+                                                                 nat.stream_ptr()))
+            fc = [torch.from_numpy(np.ascontiguousarray(full_cols[kk], dtype=np.float64)).to(device)
+                  for kk in ("dewi", "ht_mean", "hi_mean")]
+            fd = torch.empty(total_rows, dtype=torch.float32, device=device)
+            fe = torch.empty(total_rows, dtype=torch.float32, device=device)
+            nat.check(nat.load_library().dewi_payload_soa_f64(nat.ptr(fc[0]), nat.ptr(fc[1]), nat.ptr(fc[2]),
+                                                              nat.ptr(fd), nat.ptr(fe), total_rows, nat.stream_ptr()))
+            single = eng.DeviceCorpus(full, fd, fe, "cosine")
+        else:
+            single = corpus          # forced RCCL path on one GPU: compare with the plain search
+        n_chk = min(16, n_distinct)
+        bad = 0
+        for j in range(n_chk):
+            ri, rs = single.search_device(Q[j], k, eta, 0.0)
+            torch.cuda.synchronize()
+            if not (torch.equal(ri, out_ids[j]) and torch.equal(rs, out_sc[j])):
+                bad += 1
+        result["sharded_parity"] = {"queries_checked": n_chk, "mismatches_vs_single_gpu": bad}
+        if bad:
+            print(f"SHARDED PARITY FAIL: {bad}/{n_chk} queries differ from the single-GPU search", file=sys.stderr)
 
     # ------------------------------------------------------------------ p50 latency through the API
     if rank == 0 and world == 1 and args.latency_queries > 0:

@@ -242,6 +242,58 @@ int dewi_knn_rerank_f32(const float* d_E, int64_t n_rows, int dim, const float* 
                          d_out_ids, d_out_scores, d_workspace, workspace_bytes, stream);
 }
 
+int dewi_knn_scan(const void* d_E, int elem_type, int64_t n_rows, int dim, const float* d_Q, int n_queries,
+                  int n_candidates, int space, void* d_workspace, size_t workspace_bytes, void* stream_) {
+  int rc = check_common(d_E, n_rows, dim, d_Q, n_queries, space);
+  if (rc) return rc;
+  if (n_candidates <= 0) return DEWI_OK;
+  if (n_candidates > dewi::kMaxSortCandidates)
+    return fail(DEWI_ERR_UNSUPPORTED, "n_candidates %d exceeds %d", n_candidates, dewi::kMaxSortCandidates);
+  DeviceInfo dev;
+  rc = ensure_device(dev);
+  if (rc) return rc;
+  const int c_local = n_candidates < n_rows ? n_candidates : static_cast<int>(n_rows);
+  const KnnLayout L = layout_knn(n_rows, dim, elem_type ? 2 : 4, n_queries, c_local, dev.cus);
+  if (!d_workspace || workspace_bytes < L.total)
+    return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, L.total);
+  return run_scan(L, d_E, elem_type, n_rows, dim, d_Q, n_queries, c_local, space, static_cast<char*>(d_workspace),
+                  static_cast<hipStream_t>(stream_));
+}
+
+int dewi_knn_finish(const void* d_workspace, size_t workspace_bytes, int64_t n_rows, int dim, int n_queries,
+                    int n_candidates, int k, double eta, double entropy_pref, const float* d_dewi32,
+                    const float* d_ent32, int64_t id_offset, int64_t* d_out_ids, float* d_out_scores,
+                    dewi_candidate* d_out_cand, void* stream_) {
+  if (n_rows <= 0 || dim <= 0 || n_queries <= 0) return fail(DEWI_ERR_INVALID_ARG, "non-positive size");
+  if (n_candidates <= 0) return DEWI_OK;
+  if (n_candidates > dewi::kMaxSortCandidates)
+    return fail(DEWI_ERR_UNSUPPORTED, "n_candidates %d exceeds %d", n_candidates, dewi::kMaxSortCandidates);
+  if (!d_dewi32 || !d_ent32) return fail(DEWI_ERR_INVALID_ARG, "null payload pointer");
+  const bool records = d_out_cand != nullptr;
+  if (!records) {
+    if (k <= 0) return DEWI_OK;
+    if (k > n_candidates) return fail(DEWI_ERR_K_OUT_OF_BOUNDS, "kth(=%d) out of bounds (%d)", n_candidates - k, n_candidates);
+    if (!d_out_ids || !d_out_scores) return fail(DEWI_ERR_INVALID_ARG, "null output pointer");
+  } else if (id_offset < 0 || id_offset + n_rows > 0x7FFFFFFFll) {
+    return fail(DEWI_ERR_UNSUPPORTED, "global row ids must fit int32");
+  }
+  DeviceInfo dev;
+  int rc = ensure_device(dev);
+  if (rc) return rc;
+  const int c_local = n_candidates < n_rows ? n_candidates : static_cast<int>(n_rows);
+  const KnnLayout L = layout_knn(n_rows, dim, 4, n_queries, c_local, dev.cus);
+  if (!d_workspace || workspace_bytes < L.total)
+    return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, L.total);
+  const char* ws = static_cast<const char*>(d_workspace);
+  const int sorted = (L.plan.slots == 1 && c_local == n_candidates) ? L.plan.n_lists : 0;
+  hipError_t e = dewi::launch_select_rerank(reinterpret_cast<const uint64_t*>(ws + L.keys_off), L.plan.keys_per_query,
+                                            sorted, n_queries, n_candidates, records ? 0 : k,
+                                            make_rerank(records ? 0.0 : eta, records ? 0.0 : entropy_pref), d_dewi32,
+                                            d_ent32, id_offset, d_out_ids, d_out_scores, d_out_cand,
+                                            static_cast<hipStream_t>(stream_));
+  return e == hipSuccess ? DEWI_OK : hip_fail(e, "select launch");
+}
+
 int dewi_knn_rerank_bf16(const uint16_t* d_E, int64_t n_rows, int dim, const float* d_Q, int n_queries,
                          const float* d_dewi32, const float* d_ent32, int k, double eta, double entropy_pref, int space,
                          int64_t* d_out_ids, float* d_out_scores, void* d_workspace, size_t workspace_bytes,

@@ -197,6 +197,71 @@ class DeviceCorpus:
         return out
 
 
+class PipelinedSearcher:
+    """Two queries in flight on one GPU (throughput mode).
+
+    Query i's scan runs on ``scan_stream``; its finish (select, blend, top-k — or, for a doc-id
+    shard, the candidate records) runs on ``finish_stream`` from one of two workspaces, so it
+    overlaps the scan of query i+1.  Scans themselves stay back to back on one stream: nothing
+    competes with the corpus stream for HBM.  ``submit`` only enqueues; call ``drain`` (or
+    synchronise the finish stream) before reading the outputs.
+    """
+
+    def __init__(self, corpus: DeviceCorpus, k: int, eta: float, entropy_pref: float, n_queries: int = 1,
+                 n_candidates: Optional[int] = None, finish_stream=None):
+        torch = _torch()
+        self.corpus = corpus
+        self.k, self.eta, self.pref, self.b = int(k), float(eta), float(entropy_pref), int(n_queries)
+        self.c = int(n_candidates) if n_candidates is not None else min(2 * self.k, corpus.n_rows)
+        self._lib = corpus._lib
+        need = int(self._lib.dewi_knn_workspace_bytes(corpus.n_rows, corpus.dim, self.b, max(1, min(self.c, corpus.n_rows))))
+        if need == 0:
+            raise nat.NativeLibraryError("dewi_knn_workspace_bytes returned 0: " + nat.last_error())
+        self._need = need
+        with torch.cuda.device(corpus.device):
+            self.scan_stream = torch.cuda.Stream()
+            self.finish_stream = finish_stream if finish_stream is not None else torch.cuda.Stream()
+            self._ws = [torch.empty(need, dtype=torch.uint8, device=corpus.device) for _ in range(2)]
+            self._scan_done = [torch.cuda.Event() for _ in range(2)]
+            self._finish_done = [torch.cuda.Event() for _ in range(2)]
+        self._i = 0
+        self._elem = 1 if corpus.is_bf16 else 0
+        self._space = nat.SPACE_CODES[corpus.space]
+        self._emb, self._dewi, self._ent = nat.ptr(corpus.emb), nat.ptr(corpus.dewi32), nat.ptr(corpus.ent32)
+        self._s_scan, self._s_fin = int(self.scan_stream.cuda_stream), int(self.finish_stream.cuda_stream)
+
+    def submit(self, q_dev, out_ids=None, out_scores=None, out_records=None) -> None:
+        """Enqueue one query batch.  Final results go to (out_ids, out_scores); with ``out_records``
+        (int32 [B, c, 4]) the shard's candidate records are written instead."""
+        i = self._i
+        slot = i & 1
+        self._i = i + 1
+        c = self.corpus
+        if i >= 2:
+            self.scan_stream.wait_event(self._finish_done[slot])       # workspace `slot` is free again
+        rc = self._lib.dewi_knn_scan(self._emb, self._elem, c.n_rows, c.dim, q_dev.data_ptr(), self.b, self.c,
+                                     self._space, self._ws[slot].data_ptr(), self._need, self._s_scan)
+        if rc:
+            nat.check(rc)
+        self._scan_done[slot].record(self.scan_stream)
+        self.finish_stream.wait_event(self._scan_done[slot])
+        if out_records is None:
+            rc = self._lib.dewi_knn_finish(self._ws[slot].data_ptr(), self._need, c.n_rows, c.dim, self.b, self.c,
+                                           self.k, self.eta, self.pref, self._dewi, self._ent, c.id_offset,
+                                           out_ids.data_ptr(), out_scores.data_ptr(), 0, self._s_fin)
+        else:
+            rc = self._lib.dewi_knn_finish(self._ws[slot].data_ptr(), self._need, c.n_rows, c.dim, self.b, self.c,
+                                           0, 0.0, 0.0, self._dewi, self._ent, c.id_offset, 0, 0,
+                                           out_records.data_ptr(), self._s_fin)
+        if rc:
+            nat.check(rc)
+        self._finish_done[slot].record(self.finish_stream)
+
+    def drain(self) -> None:
+        self.scan_stream.synchronize()
+        self.finish_stream.synchronize()
+
+
 def merge_rerank_device(lists, n_candidates: int, k: int, eta: float, entropy_pref: float, out_ids=None,
                         out_scores=None):
     """lists: int32 [n_lists, B, list_len, 4] candidate records (the all-gather result)."""
