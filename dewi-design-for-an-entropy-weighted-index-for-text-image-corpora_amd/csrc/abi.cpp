@@ -125,17 +125,20 @@ int run_scan(const KnnLayout& L, const void* d_E, int elem_type, int64_t n_rows,
   uint64_t* keys = reinterpret_cast<uint64_t*>(ws + L.keys_off);
   float* qn = reinterpret_cast<float*>(ws + L.qn_off);
   hipError_t e;
-  if (elem_type != 0) return fail(DEWI_ERR_UNSUPPORTED, "bf16 corpus scan is not built yet");
   if (!L.plan.fast) {
-    e = dewi::launch_prepare_queries(d_Q, qn, n_queries, dim, space, stream);
+    e = dewi::launch_prepare_queries(d_Q, qn, n_queries, dim, space, elem_type ? 1 : 0, stream);
     if (e != hipSuccess) return hip_fail(e, "prepare_queries");
   }
   ScanTimer timer(stream);
   int q = 0;
   while (q < n_queries) {
     const int nq = (n_queries - q >= 4) ? 4 : 1;
-    e = dewi::launch_scan_f32(L.plan, static_cast<const float*>(d_E), n_rows, dim, d_Q, L.plan.fast ? nullptr : qn, q,
-                              nq, n_candidates, space, keys, stream);
+    if (elem_type)
+      e = dewi::launch_scan_bf16(L.plan, static_cast<const uint16_t*>(d_E), n_rows, dim, d_Q, L.plan.fast ? nullptr : qn,
+                                 q, nq, n_candidates, space, keys, stream);
+    else
+      e = dewi::launch_scan_f32(L.plan, static_cast<const float*>(d_E), n_rows, dim, d_Q, L.plan.fast ? nullptr : qn, q,
+                                nq, n_candidates, space, keys, stream);
     if (e != hipSuccess) return hip_fail(e, "scan launch");
     q += nq;
   }
@@ -231,7 +234,9 @@ size_t dewi_knn_workspace_bytes(int64_t n_rows, int dim, int n_queries, int n_ca
   DeviceInfo dev;
   if (ensure_device(dev)) return 0;
   if (n_rows <= 0 || dim <= 0 || n_queries <= 0 || n_candidates <= 0) return 0;
-  return layout_knn(n_rows, dim, 4, n_queries, n_candidates, dev.cus).total;
+  const size_t a = layout_knn(n_rows, dim, 4, n_queries, n_candidates, dev.cus).total;
+  const size_t b = layout_knn(n_rows, dim, 2, n_queries, n_candidates, dev.cus).total;
+  return a > b ? a : b;  // valid for either element type
 }
 
 int dewi_knn_rerank_f32(const float* d_E, int64_t n_rows, int dim, const float* d_Q, int n_queries,
@@ -260,8 +265,8 @@ int dewi_knn_scan(const void* d_E, int elem_type, int64_t n_rows, int dim, const
                   static_cast<hipStream_t>(stream_));
 }
 
-int dewi_knn_finish(const void* d_workspace, size_t workspace_bytes, int64_t n_rows, int dim, int n_queries,
-                    int n_candidates, int k, double eta, double entropy_pref, const float* d_dewi32,
+int dewi_knn_finish(const void* d_workspace, size_t workspace_bytes, int elem_type, int64_t n_rows, int dim,
+                    int n_queries, int n_candidates, int k, double eta, double entropy_pref, const float* d_dewi32,
                     const float* d_ent32, int64_t id_offset, int64_t* d_out_ids, float* d_out_scores,
                     dewi_candidate* d_out_cand, void* stream_) {
   if (n_rows <= 0 || dim <= 0 || n_queries <= 0) return fail(DEWI_ERR_INVALID_ARG, "non-positive size");
@@ -281,7 +286,7 @@ int dewi_knn_finish(const void* d_workspace, size_t workspace_bytes, int64_t n_r
   int rc = ensure_device(dev);
   if (rc) return rc;
   const int c_local = n_candidates < n_rows ? n_candidates : static_cast<int>(n_rows);
-  const KnnLayout L = layout_knn(n_rows, dim, 4, n_queries, c_local, dev.cus);
+  const KnnLayout L = layout_knn(n_rows, dim, elem_type ? 2 : 4, n_queries, c_local, dev.cus);
   if (!d_workspace || workspace_bytes < L.total)
     return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, L.total);
   const char* ws = static_cast<const char*>(d_workspace);

@@ -17,87 +17,9 @@
 // span of the matrix.  Query fragments live in registers for the whole kernel (the same 4*U
 // floats per lane are needed for every row), so there is no LDS traffic at all; the cross-lane
 // sum runs on the DPP crossbar.
-#include "common.hpp"
-#include "launch.hpp"
+#include "scan_common.hpp"
 
 namespace dewi {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kMaxSlots = kMaxListCandidates / kWave;  // up to 4 key registers per lane per query
-
-template <bool NT>
-__device__ __forceinline__ f32x4 load_x4(const f32x4* p) {
-  if constexpr (NT) return __builtin_nontemporal_load(p);
-  return *p;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Per-wave top-c list.  Position p = slot*64 + lane is active when p < c.  `thr` is the smallest
-// active key (the entry a better candidate replaces), `thr_s` its score for the cheap test.
-// ---------------------------------------------------------------------------------------------
-template <int kSlots>
-struct WaveList {
-  uint64_t key[kSlots];
-  uint64_t thr;
-  float thr_s;
-
-  __device__ __forceinline__ void init(int c, int lane) {
-#pragma unroll
-    for (int s = 0; s < kSlots; ++s) key[s] = (s * kWave + lane) < c ? kKeyEmpty : kKeyInactive;
-    thr = kKeyEmpty;
-    thr_s = -__builtin_inff();
-  }
-  // `score` and `row` are wave-uniform.
-  __device__ __forceinline__ void offer(float score, uint32_t row, int lane) {
-    if (score < thr_s) return;  // common case; false for NaN so NaN rows reach the exact test
-    const uint64_t k = make_key(score, row);
-    if (k <= thr) return;
-    bool placed = false;
-#pragma unroll
-    for (int s = 0; s < kSlots; ++s) {
-      const unsigned long long m = __ballot(key[s] == thr);
-      if (!placed && m != 0ull) {
-        if (lane == __ffsll(m) - 1) key[s] = k;
-        placed = true;
-      }
-    }
-    uint64_t local = key[0];
-#pragma unroll
-    for (int s = 1; s < kSlots; ++s) local = key[s] < local ? key[s] : local;
-    thr = wave_min_u64(local);
-    thr_s = thr == kKeyEmpty ? -__builtin_inff() : key_score(thr);
-  }
-  __device__ __forceinline__ void store(uint64_t* dst, int c, int lane) const {
-#pragma unroll
-    for (int s = 0; s < kSlots; ++s) {
-      const int p = s * kWave + lane;
-      if (p < c) dst[p] = key[s];
-    }
-  }
-};
-
-// Block-level merge of the per-wave lists (single-slot lists, c <= 64): every wave drops its
-// c keys into LDS, each thread ranks one key against all of them (broadcast reads), and the c best
-// leave the kernel already sorted descending.  Empty keys tie at 0 and are ordered by position.
-__device__ __forceinline__ void block_merge_store(const WaveList<1>& lst, uint64_t* __restrict__ sh,
-                                                  uint64_t* __restrict__ dst, int c, int lane, int wave_in_block) {
-  constexpr int kWavesPerBlock = kScanThreads / kWave;
-  __syncthreads();  // sh may still be read by the previous query's merge
-  if (lane < c) sh[wave_in_block * c + lane] = lst.key[0];
-  __syncthreads();
-  const int total = kWavesPerBlock * c;  // <= blockDim because c <= 64
-  const int i = static_cast<int>(threadIdx.x);
-  if (i < total) {
-    const uint64_t mine = sh[i];
-    int rank = 0;
-    for (int j = 0; j < total; ++j) {
-      const uint64_t o = sh[j];
-      rank += (o > mine || (o == mine && j < i)) ? 1 : 0;
-    }
-    if (rank < c) dst[rank] = mine;
-  }
-}
 
 template <int SPACE>
 __device__ __forceinline__ float accum4(f32x4 e, f32x4 q, float acc) {
@@ -323,7 +245,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_generic_f32(const float* __
 // Query preparation for the generic path: one wave per query, cosine -> q / ||q|| unless 0.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kWave) void prepare_queries_f32(const float* __restrict__ Q, float* __restrict__ Qn,
-                                                             int dim, int space) {
+                                                             int dim, int space, int to_bf16) {
   const int lane = lane_id();
   const float* q = Q + static_cast<int64_t>(blockIdx.x) * dim;
   float* o = Qn + static_cast<int64_t>(blockIdx.x) * dim;
@@ -335,12 +257,19 @@ __global__ __launch_bounds__(kWave) void prepare_queries_f32(const float* __rest
     norm = __fsqrt_rn(wave_sum_f32(ss));
     scale = norm > 0.f;
   }
-  for (int j = lane; j < dim; j += kWave) o[j] = scale ? __fdiv_rn(q[j], norm) : q[j];
+  for (int j = lane; j < dim; j += kWave) {
+    float v = scale ? __fdiv_rn(q[j], norm) : q[j];
+    if (to_bf16 && v == v) {  // round to nearest-even bf16, kept as the fp32 value it represents
+      const uint32_t u = __float_as_uint(v);
+      v = __uint_as_float((u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u);
+    }
+    o[j] = v;
+  }
 }
 
-hipError_t launch_prepare_queries(const float* d_q, float* d_qn, int n_queries, int dim, int space,
+hipError_t launch_prepare_queries(const float* d_q, float* d_qn, int n_queries, int dim, int space, int to_bf16,
                                   hipStream_t stream) {
-  hipLaunchKernelGGL(prepare_queries_f32, dim3(n_queries), dim3(kWave), 0, stream, d_q, d_qn, dim, space);
+  hipLaunchKernelGGL(prepare_queries_f32, dim3(n_queries), dim3(kWave), 0, stream, d_q, d_qn, dim, space, to_bf16);
   return hipGetLastError();
 }
 
@@ -356,14 +285,21 @@ static int next_pow2(int v) {
 ScanPlan plan_scan(int64_t n_rows, int dim, int elem_bytes, int n_candidates, int compute_units,
                    const Tuning& tuning) {
   ScanPlan p{};
-  (void)elem_bytes;
   const int u = dim / 256;
-  p.fast = (dim % 256 == 0) && (u == 1 || u == 2 || u == 3 || u == 4 || u == 6);
   p.dense = n_candidates > kMaxListCandidates;
-  p.vec = (dim % 4 == 0) ? 4 : 1;
-  p.group = p.fast ? kWave : (next_pow2((dim + p.vec - 1) / p.vec) > kWave ? kWave : next_pow2((dim + p.vec - 1) / p.vec));
-  p.rows_per_iter = p.fast ? (u == 1 ? 4 : (u == 2 ? 2 : 1)) : kWave / p.group;  // ~3-4 KiB in flight per wave
-  if (p.fast && tuning.rows_per_iter > 0) p.rows_per_iter = tuning.rows_per_iter;
+  if (elem_bytes == 2) {  // bf16 corpus: rows taken in pairs, 16-byte units of 8 columns
+    p.fast = (dim % 256 == 0) && (u >= 1 && u <= 4);
+    p.vec = (dim % 8 == 0) ? 8 : 1;
+    p.rows_per_iter = 2;
+  } else {
+    p.fast = (dim % 256 == 0) && (u == 1 || u == 2 || u == 3 || u == 4 || u == 6);
+    p.vec = (dim % 4 == 0) ? 4 : 1;
+    p.rows_per_iter = u == 1 ? 4 : (u == 2 ? 2 : 1);  // ~3-4 KiB in flight per wave
+    if (p.fast && tuning.rows_per_iter > 0) p.rows_per_iter = tuning.rows_per_iter;
+  }
+  const int units = (dim + p.vec - 1) / p.vec;
+  p.group = p.fast ? kWave : (next_pow2(units) > kWave ? kWave : next_pow2(units));
+  if (!p.fast) p.rows_per_iter = kWave / p.group;
   p.nontemporal = tuning.nontemporal < 0 ? true : tuning.nontemporal != 0;
   // One 8-wave workgroup per CU (8 waves x R*U KiB in flight each): 8 waves per CU measured
   // fastest on MI355X (1M x 768, R=8: 0.443 ms vs 0.448 ms at 32 waves per CU with R=4), and one

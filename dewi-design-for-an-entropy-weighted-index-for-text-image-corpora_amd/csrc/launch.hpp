@@ -23,13 +23,13 @@ struct ScanPlan {
   int blocks;         // workgroups of kScanThreads
   int waves;          // blocks * (kScanThreads / 64)
   int rows_per_iter;  // rows each wave loads before it reduces (fast path)
-  bool fast;          // dim == 256*U fp32 (U = 1..6), 16-byte aligned rows: row-per-wave kernel
+  bool fast;          // dim == 256*U (fp32: U in 1,2,3,4,6; bf16: 1..4): row-per-wave / row-pair-per-wave kernel
   bool dense;         // one key per row instead of per-wave lists
   int slots;          // key registers per lane per query: 1 (c <= 64), 4 (c <= 256), 0 (dense)
   int n_lists;        // candidate lists the scan emits per query: workgroups (slots == 1, each sorted
                       // descending) or wavefronts (slots == 4, unsorted); 0 when dense
   int group;          // generic path: lanes per row (power of two, <= 64)
-  int vec;            // generic path: 4 if rows can be read as float4, else 1
+  int vec;            // generic path: elements per 16-byte load (4 fp32 / 8 bf16) or 1 for scalar loads
   int nq_per_launch;  // queries handled by one corpus pass
   int64_t keys_per_query;  // number of uint64 keys the scan emits per query
   bool nontemporal;
@@ -46,13 +46,19 @@ ScanPlan plan_scan(int64_t n_rows, int dim, int elem_bytes, int n_candidates, in
 
 // ---- knn_scan.hip -------------------------------------------------------------------------
 // Normalises queries (cosine) into d_qn [n_queries][dim]; used by the generic scan path.
-hipError_t launch_prepare_queries(const float* d_q, float* d_qn, int n_queries, int dim, int space,
+// to_bf16: additionally round the normalised query to bf16 (stored as the fp32 value it represents).
+hipError_t launch_prepare_queries(const float* d_q, float* d_qn, int n_queries, int dim, int space, int to_bf16,
                                   hipStream_t stream);
 // One corpus pass for queries [q0, q0+nq): emits plan.keys_per_query keys per query into
 // d_keys + q * plan.keys_per_query.
 hipError_t launch_scan_f32(const ScanPlan& plan, const float* d_E, int64_t n_rows, int dim, const float* d_q_raw,
                            const float* d_q_norm, int q0, int nq, int n_candidates, int space, uint64_t* d_keys,
                            hipStream_t stream);
+
+// ---- knn_scan_bf16.hip: the same pass over a bf16 corpus
+hipError_t launch_scan_bf16(const ScanPlan& plan, const uint16_t* d_E, int64_t n_rows, int dim, const float* d_q_raw,
+                            const float* d_q_norm, int q0, int nq, int n_candidates, int space, uint64_t* d_keys,
+                            hipStream_t stream);
 
 // ---- select_rerank.hip --------------------------------------------------------------------
 struct RerankParams {

@@ -246,11 +246,11 @@ class PipelinedSearcher:
         self._scan_done[slot].record(self.scan_stream)
         self.finish_stream.wait_event(self._scan_done[slot])
         if out_records is None:
-            rc = self._lib.dewi_knn_finish(self._ws[slot].data_ptr(), self._need, c.n_rows, c.dim, self.b, self.c,
+            rc = self._lib.dewi_knn_finish(self._ws[slot].data_ptr(), self._need, self._elem, c.n_rows, c.dim, self.b, self.c,
                                            self.k, self.eta, self.pref, self._dewi, self._ent, c.id_offset,
                                            out_ids.data_ptr(), out_scores.data_ptr(), 0, self._s_fin)
         else:
-            rc = self._lib.dewi_knn_finish(self._ws[slot].data_ptr(), self._need, c.n_rows, c.dim, self.b, self.c,
+            rc = self._lib.dewi_knn_finish(self._ws[slot].data_ptr(), self._need, self._elem, c.n_rows, c.dim, self.b, self.c,
                                            0, 0.0, 0.0, self._dewi, self._ent, c.id_offset, 0, 0,
                                            out_records.data_ptr(), self._s_fin)
         if rc:

@@ -112,13 +112,13 @@ int dewi_knn_rerank_f32(const float* d_E, int64_t n_rows, int dim, const float* 
  * query i+1 on a second workspace; dewi_knn_rerank_f32 == scan + finish on one stream.
  * dewi_knn_finish writes final results (d_out_cand == NULL) or, for doc-id shards, the shard's
  * `n_candidates` best rows as dewi_candidate records (d_out_cand != NULL; d_out_ids/scores unused,
- * k ignored), exactly as dewi_knn_candidates.  n_rows/dim/n_queries/n_candidates must equal the
- * values given to dewi_knn_scan (they determine the workspace layout).  elem_type: 0 fp32, 1 bf16. */
+ * k ignored), exactly as dewi_knn_candidates.  elem_type/n_rows/dim/n_queries/n_candidates must equal
+ * the values given to dewi_knn_scan (they determine the workspace layout).  elem_type: 0 fp32, 1 bf16. */
 int dewi_knn_scan(const void* d_E, int elem_type, int64_t n_rows, int dim, const float* d_Q, int n_queries,
                   int n_candidates, int space, void* d_workspace, size_t workspace_bytes, void* stream);
 
-int dewi_knn_finish(const void* d_workspace, size_t workspace_bytes, int64_t n_rows, int dim, int n_queries,
-                    int n_candidates, int k, double eta, double entropy_pref, const float* d_dewi32,
+int dewi_knn_finish(const void* d_workspace, size_t workspace_bytes, int elem_type, int64_t n_rows, int dim,
+                    int n_queries, int n_candidates, int k, double eta, double entropy_pref, const float* d_dewi32,
                     const float* d_ent32, int64_t id_offset, int64_t* d_out_ids, float* d_out_scores,
                     dewi_candidate* d_out_cand, void* stream);
 

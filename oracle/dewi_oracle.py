@@ -130,6 +130,31 @@ def search(E: np.ndarray, query: np.ndarray, dewi32: np.ndarray, ent32: np.ndarr
     return ids, adj
 
 
+def search_prepared(E: np.ndarray, q_prepared: np.ndarray, dewi32: np.ndarray, ent32: np.ndarray, k: int,
+                    eta: float, entropy_pref: float = 0.0, space: str = "cosine"):
+    """``search`` without the query-normalisation step (the query is used as given)."""
+    scores = similarities(E, np.asarray(q_prepared, dtype=np.float32), space)
+    cand = candidate_cut(scores, k)
+    if cand.size == 0:
+        return np.empty(0, np.int64), np.empty(0, np.float32)
+    return rerank(cand, scores[cand], dewi32, ent32, k, eta, entropy_pref)
+
+
+def bf16_round(x: np.ndarray) -> np.ndarray:
+    """fp32 -> nearest-even bfloat16, returned as the fp32 values bf16 can hold (NaN kept).
+
+    Config C3 stores the normalised corpus and the normalised query in bf16; products of two bf16
+    values are exact in fp32, so running the fp32 restatement on rounded inputs IS the bf16 oracle.
+    """
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    u = x.view(np.uint32)
+    r = ((u.astype(np.uint64) + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    out = r.view(np.float32).copy()
+    nan = np.isnan(x)
+    out[nan] = x[nan]
+    return out.reshape(x.shape)
+
+
 # ---------------------------------------------------------------------------
 # f64 companion used by the parity harness to decide which queries are
 # "decisive" (SURVEY.md §8(a) note 5): fp32 summation order differs between
@@ -143,12 +168,16 @@ def decision_gaps(E: np.ndarray, query: np.ndarray, dewi32: np.ndarray, ent32: n
     gap among ranks 1..k+1), computed in float64 from the fp32 inputs.  ``exact=False``
     takes the similarities from the fp32 product instead (for corpora where an f64 copy of
     the matrix is too expensive); the gaps then carry ~1e-7 of noise themselves."""
+    prepared = space == "prepared"      # cosine scores of a query that is used as given
+    if prepared:
+        space = "cosine"
+    qp = np.asarray(query, dtype=np.float32) if prepared else prepare_query(query, space)
     if exact:
-        q = prepare_query(query, space).astype(np.float64)
+        q = qp.astype(np.float64)
         E64 = E.astype(np.float64)
         s = E64 @ q if space == "cosine" else -np.sum((E64 - q[None, :]) ** 2, axis=1)
     else:
-        s = similarities(E, prepare_query(query, space), space).astype(np.float64)
+        s = similarities(E, qp, space).astype(np.float64)
     n = s.shape[0]
     c = min(2 * k, n)
     order = np.argsort(-s, kind="stable")

@@ -1,0 +1,63 @@
+"""GPU parity tests of the bf16-corpus search (config C3's storage) through the C ABI.
+
+Oracle: the fp32 restatement of the reference run on bf16-ROUNDED inputs (products of bf16 values
+are exact in fp32).  Tolerance: the GPU and NumPy normalise the query with differently ordered fp32
+sums, so a query element that sits on a bf16 rounding boundary can round the other way (one bf16
+ulp = 2^-8 relative on ONE of the d products, <= ~5e-6 on a unit-norm score).  Scores are therefore
+compared to 2e-5 and the id ranking only where decision gaps exceed 2e-5.
+"""
+import numpy as np
+import pytest
+
+import dewi_oracle as orc
+from parity import check_batch
+
+pytestmark = pytest.mark.gpu
+TOL = dict(gap=2e-5, score_tol=2e-5, prepared=True)
+
+
+def _setup(n, dim, seed):
+    from dewi import _engine as eng
+    raw = orc.synth_corpus(n, dim, seed=seed)
+    cols = orc.synth_payload_columns(n, seed=seed)
+    c32 = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    cb = c32.to_bf16()
+    Eb = cb.emb.float().cpu().numpy()
+    # device rounding == oracle rounding of the same stored fp32 rows
+    assert np.array_equal(Eb, orc.bf16_round(c32.emb.cpu().numpy()))
+    dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    return cb, Eb, dewi32, ent32
+
+
+@pytest.mark.parametrize("dim,n", [(768, 4001), (768, 4000), (512, 3000), (256, 2501), (1024, 1501), (136, 2000),
+                                   (100, 2000), (1280, 900)])
+def test_bf16_search_vs_oracle(dim, n):
+    """Fast pair-of-rows kernel (dim = 256*H, odd and even row counts), 16-byte generic, scalar generic."""
+    cb, Eb, dewi32, ent32 = _setup(n, dim, seed=dim + n)
+    Q = orc.synth_queries(5, dim, seed=dim)
+    Qp = np.stack([orc.bf16_round(orc.prepare_query(q)) for q in Q])
+    for k, eta, pref in ((10, 0.3, 0.0), (1, 0.5, 0.0), (100, 0.25, 0.3), (150, 0.5, 0.0)):
+        ids, sc = cb.search(Q, k, eta, pref)
+        # with 100+ results some adjacent pair is almost always closer than 2e-5: those queries are
+        # checked as score multisets only, so no bound on their share
+        check_batch(Eb, Qp, dewi32, ent32, k, eta, pref, "cosine", ids, sc,
+                    max_excluded_frac=0.6 if k <= 10 else 1.0, **TOL)
+
+
+def test_bf16_sharded_equals_whole():
+    from dewi import _engine as eng
+    import torch
+    n, d, k = 6000, 768, 10
+    raw = orc.synth_corpus(n, d, seed=5)
+    cols = orc.synth_payload_columns(n, seed=5)
+    Q = orc.synth_queries(4, d, seed=6)
+    whole = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"]).to_bf16()
+    ids_ref, sc_ref = whole.search(Q, k, 0.3, 0.0)
+    qd = torch.from_numpy(Q).cuda()
+    lists = []
+    for lo, hi in ((0, 2500), (2500, 6000)):                       # even boundaries: row pairs stay aligned
+        sub = {key: v[lo:hi] for key, v in cols.items()}
+        sh = eng.DeviceCorpus.from_host(raw[lo:hi], sub["dewi"], sub["ht_mean"], sub["hi_mean"], id_offset=lo).to_bf16()
+        lists.append(sh.candidates_device(qd, 2 * k))
+    ids, sc = eng.merge_rerank_device(torch.stack(lists), 2 * k, k, 0.3, 0.0)
+    assert np.array_equal(ids.cpu().numpy(), ids_ref) and np.array_equal(sc.cpu().numpy(), sc_ref)
