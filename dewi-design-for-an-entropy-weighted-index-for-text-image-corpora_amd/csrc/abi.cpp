@@ -57,7 +57,7 @@ int ensure_device(DeviceInfo& out) {
   return DEWI_OK;
 }
 
-dewi::Tuning g_tuning{0, 0, -1};
+dewi::Tuning g_tuning{0, 0, -1, 1};
 
 // ---- timing ring -----------------------------------------------------------------------------
 struct Timing {
@@ -174,15 +174,32 @@ int knn_rerank_impl(const void* d_E, int elem_type, int64_t n_rows, int dim, con
   DeviceInfo dev;
   rc = ensure_device(dev);
   if (rc) return rc;
+  char* ws = static_cast<char*>(d_ws);
+  if (elem_type == 1 && g_tuning.mfma != 0 && dewi::mfma_path_supported(n_rows, dim, n_queries, c, space)) {
+    // many queries over a bf16 corpus: matrix-core path, one corpus pass per 256 queries
+    const dewi::MfmaLayout M = dewi::plan_mfma(n_rows, dim, n_queries, c);
+    if (!d_ws || ws_bytes < M.total) return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, M.total);
+    hipError_t e;
+    {
+      ScanTimer timer(stream);
+      e = dewi::launch_mfma_bf16(M, static_cast<const uint16_t*>(d_E), n_rows, dim, d_Q, n_queries, c, space, ws, dev.cus,
+                                 stream);
+    }
+    if (e != hipSuccess) return hip_fail(e, "mfma scan launch");
+    e = dewi::launch_select_rerank(reinterpret_cast<const uint64_t*>(ws + M.cand_off), M.capq, 0, n_queries, c, k,
+                                   make_rerank(eta, pref), d_dewi32, d_ent32, 0, d_out_ids, d_out_scores, nullptr,
+                                   reinterpret_cast<const uint32_t*>(ws + M.cnt_off), stream);
+    if (e != hipSuccess) return hip_fail(e, "select_rerank launch");
+    return DEWI_OK;
+  }
   const KnnLayout L = layout_knn(n_rows, dim, elem_type ? 2 : 4, n_queries, c, dev.cus);
   if (!d_ws || ws_bytes < L.total) return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, L.total);
-  char* ws = static_cast<char*>(d_ws);
   rc = run_scan(L, d_E, elem_type, n_rows, dim, d_Q, n_queries, c, space, ws, stream);
   if (rc) return rc;
   const dewi::RerankParams rp = make_rerank(eta, pref);
   hipError_t e = dewi::launch_select_rerank(reinterpret_cast<const uint64_t*>(ws + L.keys_off), L.plan.keys_per_query,
                                             L.plan.slots == 1 ? L.plan.n_lists : 0, n_queries, c, k, rp, d_dewi32, d_ent32, 0, d_out_ids, d_out_scores, nullptr,
-                                            stream);
+                                            nullptr, stream);
   if (e != hipSuccess) return hip_fail(e, "select_rerank launch");
   return DEWI_OK;
 }
@@ -234,9 +251,14 @@ size_t dewi_knn_workspace_bytes(int64_t n_rows, int dim, int n_queries, int n_ca
   DeviceInfo dev;
   if (ensure_device(dev)) return 0;
   if (n_rows <= 0 || dim <= 0 || n_queries <= 0 || n_candidates <= 0) return 0;
-  const size_t a = layout_knn(n_rows, dim, 4, n_queries, n_candidates, dev.cus).total;
+  size_t a = layout_knn(n_rows, dim, 4, n_queries, n_candidates, dev.cus).total;
   const size_t b = layout_knn(n_rows, dim, 2, n_queries, n_candidates, dev.cus).total;
-  return a > b ? a : b;  // valid for either element type
+  if (b > a) a = b;
+  if (dewi::mfma_path_supported(n_rows, dim, n_queries, n_candidates, DEWI_SPACE_COSINE)) {
+    const size_t m = dewi::plan_mfma(n_rows, dim, n_queries, n_candidates).total;
+    if (m > a) a = m;
+  }
+  return a;  // valid for either element type and either bf16 path
 }
 
 int dewi_knn_rerank_f32(const float* d_E, int64_t n_rows, int dim, const float* d_Q, int n_queries,
@@ -294,7 +316,7 @@ int dewi_knn_finish(const void* d_workspace, size_t workspace_bytes, int elem_ty
   hipError_t e = dewi::launch_select_rerank(reinterpret_cast<const uint64_t*>(ws + L.keys_off), L.plan.keys_per_query,
                                             sorted, n_queries, n_candidates, records ? 0 : k,
                                             make_rerank(records ? 0.0 : eta, records ? 0.0 : entropy_pref), d_dewi32,
-                                            d_ent32, id_offset, d_out_ids, d_out_scores, d_out_cand,
+                                            d_ent32, id_offset, d_out_ids, d_out_scores, d_out_cand, nullptr,
                                             static_cast<hipStream_t>(stream_));
   return e == hipSuccess ? DEWI_OK : hip_fail(e, "select launch");
 }
@@ -337,7 +359,7 @@ int dewi_knn_candidates(const void* d_E, int elem_type, int64_t n_rows, int dim,
   hipError_t e = dewi::launch_select_rerank(reinterpret_cast<const uint64_t*>(ws + L.keys_off), L.plan.keys_per_query,
                                             (L.plan.slots == 1 && c_local == n_candidates) ? L.plan.n_lists : 0,
                                             n_queries, n_candidates, 0, rp, d_dewi32, d_ent32, id_offset, nullptr,
-                                            nullptr, d_out, stream);
+                                            nullptr, d_out, nullptr, stream);
   if (e != hipSuccess) return hip_fail(e, "select (candidates) launch");
   return DEWI_OK;
 }
@@ -418,10 +440,11 @@ int dewi_timing_read(double* out_mean_scan_ms, int* out_launches) {
   return DEWI_OK;
 }
 
-int dewi_tuning_set(int scan_blocks, int rows_per_iter, int nontemporal) {
+int dewi_tuning_set(int scan_blocks, int rows_per_iter, int nontemporal, int batched_mfma) {
   g_tuning.scan_blocks = scan_blocks;
   g_tuning.rows_per_iter = rows_per_iter;
   g_tuning.nontemporal = nontemporal;
+  g_tuning.mfma = batched_mfma;
   return DEWI_OK;
 }
 

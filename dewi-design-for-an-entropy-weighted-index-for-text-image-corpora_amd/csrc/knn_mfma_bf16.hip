@@ -1,0 +1,335 @@
+// Batched kNN over a bf16 corpus on the matrix cores (config C3: 1M x 768 bf16, 256 queries,
+// k = 100), gfx950 (MI355X).
+//
+// Same contract as the scan kernels — steps 1-3 of ExactIndex.search (reference
+// src/dewi/backends.py:420-444) — for up to 256 queries per corpus pass: the 256 x N score matrix
+// S = Qb * Eb^T is computed tile by tile with v_mfma_f32_32x32x16_bf16 and never written; an
+// epilogue keeps only scores that can still reach the top c.
+//
+// Roofline: co-limited.  Algorithmic bytes per pass = n_rows*dim*2 (HBM, read once); flops =
+// 2*256*n_rows*dim (393 GFLOP at C3) -> 256 flop/B against a ~310 flop/B machine balance.
+//
+// Structure (one 4-wave workgroup per CU — one wave per SIMD, each with the whole 512-register
+// file — persistent over 32-document tiles):
+//  * QUERIES LIVE IN REGISTERS.  Wave w owns queries 64w..64w+63 for the whole kernel: their B
+//    fragments (2 x dim/16 x 4 VGPRs = 384 at dim 768) are loaded once.  No query traffic, no LDS
+//    for Q, and every A fragment read from LDS feeds two MFMAs.
+//  * DOCUMENT TILES GO THROUGH LDS BY DMA.  A tile (32 rows x dim bf16 = 48 KiB) is copied
+//    global->LDS with global_load_lds_dwordx4 (1 KiB per wave-instruction, no VGPR staging),
+//    double-buffered: tile i+1 is in flight while tile i is multiplied (counted vmcnt, raw
+//    s_barrier).  All 4 waves read the same tile (A operand) with ds_read_b128.
+//  * BANK CONFLICTS: rows are 1536 B apart (= 0 mod 256 B), so an A-fragment read (16 lanes = 16
+//    rows, same 16-byte column unit) would be 16-way conflicted.  The LDS image is linear (DMA
+//    writes base + lane*16) and the SOURCE address is permuted instead: unit c of row r is stored
+//    at unit (c & ~15) | ((c & 15) ^ (r & 15)); reads apply the same XOR -> conflict-free.
+//  * EPILOGUE.  D[doc][query]: lane l holds query l&31 and 16 documents.  Filter mode: a score
+//    passes if it is not below the query's threshold (a lower bound of its final c-th best score,
+//    from a strided 1/32 sample of the corpus scanned in dense mode first); survivors are appended
+//    to the query's candidate buffer with one global atomic each (~32c per query over the pass).
+//    If a buffer overflows (only for adversarial corpora, e.g. tens of thousands of exact
+//    duplicates of a top document) the count keeps growing and the finish kernel flags the query.
+#include "select_common.hpp"
+
+namespace dewi {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4m __attribute__((ext_vector_type(4)));
+
+constexpr int kMfmaThreads = 256;     // 4 waves, one per SIMD: each owns 64 queries and the whole 512-register file
+constexpr int kTileRows = 32;
+constexpr int kQueriesPerPass = 256;  // 4 waves x 64
+constexpr int kSampleStride = 32;     // every 32nd tile is a sample tile
+
+using GlobalPtr = const void __attribute__((address_space(1)))*;
+using LdsPtr = void __attribute__((address_space(3)))*;
+
+// Query preparation: normalise (cosine, unless the norm is 0) and round to bf16; rows >= n_queries
+// of the 32-padded block are zero.  One wave per query row.
+__global__ __launch_bounds__(kWave) void prepare_queries_bf16(const float* __restrict__ Q, uint16_t* __restrict__ Qb,
+                                                              int n_queries, int dim, int space) {
+  const int lane = lane_id();
+  const int row = static_cast<int>(blockIdx.x);
+  uint16_t* o = Qb + static_cast<int64_t>(row) * dim;
+  if (row >= n_queries) {
+    for (int j = lane; j < dim; j += kWave) o[j] = 0;
+    return;
+  }
+  const float* q = Q + static_cast<int64_t>(row) * dim;
+  float norm = 1.f;
+  bool scale = false;
+  if (space == DEWI_SPACE_COSINE) {
+    float ss = 0.f;
+    for (int j = lane; j < dim; j += kWave) ss = __builtin_fmaf(q[j], q[j], ss);
+    norm = __fsqrt_rn(wave_sum_f32(ss));
+    scale = norm > 0.f;
+  }
+  for (int j = lane; j < dim; j += kWave) {
+    const float v = scale ? __fdiv_rn(q[j], norm) : q[j];
+    const uint32_t u = __float_as_uint(v);
+    o[j] = (v != v) ? static_cast<uint16_t>((u >> 16) | 0x0040u)
+                    : static_cast<uint16_t>((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+  }
+}
+
+// KS = dim / 16 MFMA k-steps (dim % 128 == 0, dim <= 768).
+// Tiles handled by this launch: t = first_tile + i * tile_stride, i in [0, n_tiles).
+template <int KS, bool DENSE>
+__global__ __launch_bounds__(kMfmaThreads, 1) void mfma_scan_bf16(
+    const uint16_t* __restrict__ E, int64_t n_rows, const uint16_t* __restrict__ Qb, int64_t n_tiles,
+    int64_t tile_stride, const float* __restrict__ thr, uint64_t* __restrict__ out, int64_t out_stride,
+    uint32_t* __restrict__ cnt) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the body holds gfx950 inline asm: the host pass only needs the launch stub
+  constexpr int DIM = KS * 16;
+  constexpr int UPR = DIM / 8;                     // 16-byte units per row
+  constexpr int TILE_BYTES = kTileRows * DIM * 2;
+  constexpr int PIECES = TILE_BYTES / 1024;        // 1 KiB DMA pieces per tile (= KS)
+  constexpr int NW = kMfmaThreads / kWave;         // waves per workgroup
+  constexpr int PPW = PIECES / NW;                 // pieces per wave
+  static_assert(KS % 8 == 0 && KS <= 48, "dim must be a multiple of 128, at most 768");
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // 2 x TILE_BYTES
+
+  const int lane = lane_id();
+  const int wave = static_cast<int>(threadIdx.x) >> 6;
+  const int r = lane & 31, h = lane >> 5;
+
+  // ---- query fragments (B operand): two 32-query blocks per wave; lane holds
+  //      Qb[64*wave + 32*b + r][16 s + 8 h .. +7]
+  bf16x8 qf[2][KS];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const bf16x8* qp = reinterpret_cast<const bf16x8*>(Qb + static_cast<int64_t>(64 * wave + 32 * b + r) * DIM + 8 * h);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qf[b][s] = qp[2 * s];
+  }
+  float thr_l[2] = {-__builtin_inff(), -__builtin_inff()};
+  if constexpr (!DENSE) {
+    thr_l[0] = thr[64 * wave + r];
+    thr_l[1] = thr[64 * wave + 32 + r];
+  }
+  // Pin the compiler's waits for these loads HERE, before any DMA is in flight: their first real use
+  // is inside the tile loop, and a compiler-inserted vmcnt(0) there would drain the prefetch of the
+  // next tile on every iteration.
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    asm volatile("" ::"v"(qf[0][s]));
+    asm volatile("" ::"v"(qf[1][s]));
+  }
+  asm volatile("" ::"v"(thr_l[0]), "v"(thr_l[1]));
+
+  // ---- per-lane DMA source offsets (bytes from the tile's first row), one per piece this wave moves
+  uint32_t voff[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int piece = i * NW + wave;
+    const int x = piece * 64 + lane;               // LDS unit this lane fills
+    const int row = x / UPR, cp = x % UPR;
+    const int c = (cp & ~15) | ((cp & 15) ^ (row & 15));
+    voff[i] = static_cast<uint32_t>(row * (DIM * 2) + c * 16);
+  }
+  // ---- per-lane A-fragment read offsets inside a tile buffer
+  const int z = (r & 15) ^ h;
+  uint32_t a_off[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a_off[j] = static_cast<uint32_t>(r * UPR * 16 + 16 * ((2 * j) ^ z));
+
+  // A tile is fetched through a buffer descriptor whose base is the tile's first row and whose
+  // size is the tile's valid bytes: rows past the end of the corpus (partial last tile) read as
+  // zeros through the hardware range check, and the per-lane part of the address is one 32-bit
+  // register per piece.
+  const char* Eb = reinterpret_cast<const char*>(E);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto issue_tile = [&](int64_t tile_index, int buf) {
+    const int64_t row0 = tile_index * kTileRows;
+    const int64_t left = n_rows - row0;
+    const int valid_rows = left < kTileRows ? static_cast<int>(left) : kTileRows;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(Eb + row0 * (DIM * 2)), 0, valid_rows * (DIM * 2), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      char* l = lds + buf * TILE_BYTES + (i * NW + wave_u) * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)(l), 16, voff[i], 0, 0, 0);
+    }
+  };
+
+  const int64_t first = static_cast<int64_t>(blockIdx.x);
+  const int64_t step = static_cast<int64_t>(gridDim.x);
+  if (first < n_tiles) issue_tile(first * tile_stride, 0);
+  int buf = 0;
+  for (int64_t i = first; i < n_tiles; i += step) {
+    const int64_t tile = i * tile_stride;
+    const bool has_next = i + step < n_tiles;
+    if (has_next) issue_tile((i + step) * tile_stride, buf ^ 1);
+    // wait for THIS tile's pieces (the newer PPW pieces of the next tile may stay in flight)
+    if (has_next) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                   // every wave's pieces of this tile have landed
+    asm volatile("" ::: "memory");
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[0][j] = acc[1][j] = 0.f;
+    // A fragments are read two k-steps ahead of the MFMAs that consume them (each feeds two MFMAs,
+    // 64 cycles of matrix work per read).  hipcc sinks plain LDS loads back next to their use at this
+    // register pressure, so the reads and their counted waits are inline asm: LDS returns data in
+    // order, hence before step s may start at most the two younger reads (s+1, s+2) may be pending.
+    // The wait statement takes the fragment as an in/out operand so that the MFMAs cannot be
+    // scheduled above it.  No other LGKM operation is issued inside this block.
+    const uint32_t tile_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((LdsPtr)(lds))) + buf * TILE_BYTES;
+    uint32_t a_addr[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a_addr[j] = tile_lds + a_off[j];
+    u32x4m a0, a1, a2;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(a0) : "v"(a_addr[0]));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(a1) : "v"(a_addr[1]));
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if (s + 2 < KS) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a2) : "v"(a_addr[(s + 2) & 7]), "n"(256 * ((s + 2) >> 3)));
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a0));
+      } else if (s + 1 < KS) {
+        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a0));
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0));
+      }
+      const bf16x8 a = __builtin_bit_cast(bf16x8, a0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[0][s], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[1][s], acc[1], 0, 0, 0);
+      a0 = a1;
+      a1 = a2;
+    }
+
+    // ---- epilogue: D[doc = (j&3) + 8*(j>>2) + 4*h][query = 64*wave + 32*b + r]
+    const int64_t row0 = tile * kTileRows;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int q = 64 * wave + 32 * b + r;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int local = (j & 3) + 8 * (j >> 2) + 4 * h;
+        const int64_t doc = row0 + local;
+        const float sc = acc[b][j];
+        if constexpr (DENSE) {
+          out[static_cast<int64_t>(q) * out_stride + i * kTileRows + local] =
+              doc < n_rows ? make_key(sc, static_cast<uint32_t>(doc)) : kKeyEmpty;
+        } else {
+          if (doc < n_rows && !(sc < thr_l[b])) {    // NaN passes (NumPy ranks NaN first)
+            const uint32_t slot = atomicAdd(&cnt[q], 1u);
+            if (static_cast<int64_t>(slot) < out_stride)
+              out[static_cast<int64_t>(q) * out_stride + slot] = make_key(sc, static_cast<uint32_t>(doc));
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                   // all waves finished reading buf before it is refilled
+    buf ^= 1;
+  }
+#endif
+}
+
+// Per-query threshold from the dense sample keys: the score of the c-th best sample document is a
+// lower bound of the query's final c-th best score.  One workgroup per query.
+__global__ __launch_bounds__(kSelectThreads) void sample_threshold_kernel(const uint64_t* __restrict__ dense,
+                                                                          int64_t n_sample, int64_t stride,
+                                                                          int n_candidates, float* __restrict__ thr) {
+  __shared__ SelectShared sh;
+  const int q = static_cast<int>(blockIdx.x);
+  const uint64_t key = block_kth_largest(dense + static_cast<int64_t>(q) * stride, n_sample,
+                                         static_cast<uint32_t>(n_candidates), sh);
+  if (threadIdx.x == 0) thr[q] = key <= 1ull ? -__builtin_inff() : key_score(key);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+bool mfma_path_supported(int64_t n_rows, int dim, int n_queries, int n_candidates, int space) {
+  return space == DEWI_SPACE_COSINE && n_queries >= 16 && dim % 128 == 0 && dim <= 768 &&
+         n_rows >= 64 * 1024 && n_candidates <= kMaxSortCandidates &&
+         n_rows / (kTileRows * kSampleStride) * kTileRows >= 4 * static_cast<int64_t>(n_candidates);
+}
+
+MfmaLayout plan_mfma(int64_t n_rows, int dim, int n_queries, int n_candidates) {
+  MfmaLayout m{};
+  auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+  m.groups = (n_queries + kQueriesPerPass - 1) / kQueriesPerPass;
+  m.q_pad = m.groups * kQueriesPerPass;
+  m.n_tiles = (n_rows + kTileRows - 1) / kTileRows;
+  m.n_sample_tiles = (m.n_tiles + kSampleStride - 1) / kSampleStride;
+  m.sample_stride = static_cast<int64_t>(m.n_sample_tiles) * kTileRows;
+  // expected survivors per query ~ n_rows * c / n_sample = 32 c; 4x head-room, at least 4096
+  int64_t cap = 4ll * kSampleStride * n_candidates;
+  m.capq = cap < 4096 ? 4096 : cap;
+  size_t off = 0;
+  m.qb_off = off;      off += up(static_cast<size_t>(m.q_pad) * dim * 2);
+  m.thr_off = off;     off += up(static_cast<size_t>(m.q_pad) * 4);
+  m.cnt_off = off;     off += up(static_cast<size_t>(m.q_pad) * 4);
+  m.dense_off = off;   off += up(static_cast<size_t>(kQueriesPerPass) * m.sample_stride * 8);
+  m.cand_off = off;    off += up(static_cast<size_t>(m.q_pad) * m.capq * 8);
+  m.total = off;
+  return m;
+}
+
+template <int KS>
+static hipError_t run_mfma_dim(const MfmaLayout& m, const uint16_t* E, int64_t n_rows, int n_candidates, char* ws,
+                               int compute_units, hipStream_t stream) {
+  constexpr int DIM = KS * 16;
+  const int lds_bytes = 2 * kTileRows * DIM * 2;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan_bf16<KS, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan_bf16<KS, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const uint16_t* qb = reinterpret_cast<const uint16_t*>(ws + m.qb_off);
+  float* thr = reinterpret_cast<float*>(ws + m.thr_off);
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(ws + m.cnt_off);
+  uint64_t* dense = reinterpret_cast<uint64_t*>(ws + m.dense_off);
+  uint64_t* cand = reinterpret_cast<uint64_t*>(ws + m.cand_off);
+  for (int g = 0; g < m.groups; ++g) {
+    const uint16_t* qg = qb + static_cast<int64_t>(g) * kQueriesPerPass * DIM;
+    float* tg = thr + g * kQueriesPerPass;
+    uint32_t* cg = cnt + g * kQueriesPerPass;
+    uint64_t* og = cand + static_cast<int64_t>(g) * kQueriesPerPass * m.capq;
+    // 1. dense scores of the strided sample
+    const int sample_blocks = m.n_sample_tiles < compute_units ? static_cast<int>(m.n_sample_tiles) : compute_units;
+    hipLaunchKernelGGL((mfma_scan_bf16<KS, true>), dim3(sample_blocks), dim3(kMfmaThreads), lds_bytes, stream, E, n_rows,
+                       qg, m.n_sample_tiles, static_cast<int64_t>(kSampleStride), static_cast<const float*>(nullptr),
+                       dense, m.sample_stride, static_cast<uint32_t*>(nullptr));
+    // 2. per-query threshold
+    hipLaunchKernelGGL(sample_threshold_kernel, dim3(kQueriesPerPass), dim3(kSelectThreads), 0, stream, dense,
+                       m.sample_stride, m.sample_stride, n_candidates, tg);
+    // 3. full pass with the filter
+    const int blocks = m.n_tiles < compute_units ? static_cast<int>(m.n_tiles) : compute_units;
+    hipLaunchKernelGGL((mfma_scan_bf16<KS, false>), dim3(blocks), dim3(kMfmaThreads), lds_bytes, stream, E, n_rows, qg,
+                       m.n_tiles, static_cast<int64_t>(1), static_cast<const float*>(tg), og, m.capq, cg);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_mfma_bf16(const MfmaLayout& m, const uint16_t* d_E, int64_t n_rows, int dim, const float* d_Q,
+                            int n_queries, int n_candidates, int space, char* ws, int compute_units,
+                            hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(ws + m.cnt_off, 0, static_cast<size_t>(m.q_pad) * 4, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(prepare_queries_bf16, dim3(m.q_pad), dim3(kWave), 0, stream, d_Q,
+                     reinterpret_cast<uint16_t*>(ws + m.qb_off), n_queries, dim, space);
+  switch (dim / 16) {
+    case 8: return run_mfma_dim<8>(m, d_E, n_rows, n_candidates, ws, compute_units, stream);
+    case 16: return run_mfma_dim<16>(m, d_E, n_rows, n_candidates, ws, compute_units, stream);
+    case 24: return run_mfma_dim<24>(m, d_E, n_rows, n_candidates, ws, compute_units, stream);
+    case 32: return run_mfma_dim<32>(m, d_E, n_rows, n_candidates, ws, compute_units, stream);
+    case 40: return run_mfma_dim<40>(m, d_E, n_rows, n_candidates, ws, compute_units, stream);
+    case 48: return run_mfma_dim<48>(m, d_E, n_rows, n_candidates, ws, compute_units, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace dewi

@@ -39,6 +39,7 @@ struct Tuning {
   int scan_blocks;
   int rows_per_iter;
   int nontemporal;  // -1 planner default, 0 off, 1 on
+  int mfma;         // batched bf16 matrix-core path: 0 off, anything else on
 };
 
 ScanPlan plan_scan(int64_t n_rows, int dim, int elem_bytes, int n_candidates, int compute_units,
@@ -60,6 +61,23 @@ hipError_t launch_scan_bf16(const ScanPlan& plan, const uint16_t* d_E, int64_t n
                             const float* d_q_norm, int q0, int nq, int n_candidates, int space, uint64_t* d_keys,
                             hipStream_t stream);
 
+// ---- knn_mfma_bf16.hip: batched (up to 256 queries per corpus pass) bf16 path on the matrix cores
+struct MfmaLayout {
+  int groups;              // passes of up to 256 queries
+  int q_pad;               // groups * 256
+  int64_t n_tiles;         // 32-row tiles
+  int64_t n_sample_tiles;  // every 32nd tile
+  int64_t sample_stride;   // dense sample keys per query (n_sample_tiles * 32)
+  int64_t capq;            // candidate-buffer capacity per query
+  size_t qb_off, thr_off, cnt_off, dense_off, cand_off, total;
+};
+bool mfma_path_supported(int64_t n_rows, int dim, int n_queries, int n_candidates, int space);
+MfmaLayout plan_mfma(int64_t n_rows, int dim, int n_queries, int n_candidates);
+// Fills cand keys [q_pad][capq] and counts [q_pad] in the workspace for every query.
+hipError_t launch_mfma_bf16(const MfmaLayout& m, const uint16_t* d_E, int64_t n_rows, int dim, const float* d_Q,
+                            int n_queries, int n_candidates, int space, char* ws, int compute_units,
+                            hipStream_t stream);
+
 // ---- select_rerank.hip --------------------------------------------------------------------
 struct RerankParams {
   float w_sim;   // fp32(1 - eta)
@@ -70,10 +88,12 @@ struct RerankParams {
 // keys [n_queries][keys_per_query] -> top n_candidates by key -> either final (ids, scores) or
 // sorted candidate records.
 // sorted_lists > 0: the keys are `sorted_lists` lists of n_candidates keys, each sorted descending.
+// d_counts (may be NULL): number of valid keys per query (<= keys_per_query); a count ABOVE
+// keys_per_query marks an overflowed candidate buffer: that query's ids are set to -1, scores to NaN.
 hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, int sorted_lists, int n_queries,
                                 int n_candidates, int k, const RerankParams& rp, const float* d_dewi32, const float* d_ent32,
                                 int64_t id_offset, int64_t* d_out_ids, float* d_out_scores,
-                                dewi_candidate* d_out_cand, hipStream_t stream);
+                                dewi_candidate* d_out_cand, const uint32_t* d_counts, hipStream_t stream);
 hipError_t launch_merge_rerank(const dewi_candidate* d_lists, int n_lists, int n_queries, int list_len,
                                int n_candidates, int k, const RerankParams& rp, int64_t* d_out_ids,
                                float* d_out_scores, hipStream_t stream);

@@ -6,117 +6,9 @@
 //   argpartition(adj, -k)[-k:], argsort(-adj)              -> bitonic sort in LDS, first k
 // One workgroup per query.  The work is O(keys) with keys << corpus bytes; this kernel is
 // latency-bound, not bandwidth-bound, and is kept to a handful of passes over L2-resident keys.
-#include "common.hpp"
-#include "launch.hpp"
+#include "select_common.hpp"
 
 namespace dewi {
-
-struct SelectShared {
-  uint64_t sel[kMaxSortCandidates];   // selected candidate keys, then sorted descending
-  uint64_t sel2[kMaxSortCandidates];  // re-rank keys
-  uint32_t val[kMaxSortCandidates];   // payload carried through the first sort (merge path)
-  uint32_t hist[256];
-  uint32_t wave_tot[4];
-  uint32_t pick_digit, pick_above, pick_count, total;
-  uint32_t count;
-};
-
-// Descending bitonic sort of p2 (power of two) keys in LDS, optional 32-bit payload.
-template <bool WITH_VAL>
-__device__ void bitonic_sort_desc(uint64_t* key, uint32_t* val, int p2) {
-  const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
-  for (int size = 2; size <= p2; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      __syncthreads();
-      for (int t = tid; t < (p2 >> 1); t += nt) {
-        const int lo = 2 * t - (t & (stride - 1));
-        const int hi = lo + stride;
-        const bool first_half = (lo & size) == 0;
-        const uint64_t a = key[lo], b = key[hi];
-        if (first_half ? (a < b) : (a > b)) {
-          key[lo] = b;
-          key[hi] = a;
-          if constexpr (WITH_VAL) {
-            const uint32_t va = val[lo];
-            val[lo] = val[hi];
-            val[hi] = va;
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-}
-
-// Descending sort by ranking: thread t counts the keys that beat src[t] (broadcast LDS reads) and
-// drops it at that position of dst.  O(n^2 / threads) work but a single barrier, which beats the
-// log^2(n) barriers of the bitonic network for the few dozen keys the usual query ends with.
-// Equal keys (only the empty key can repeat) are ordered by position.  src != dst.
-constexpr int kRankSortMax = 256;
-__device__ void rank_sort_desc(const uint64_t* src, uint64_t* dst, int n) {
-  const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
-  for (int t = tid; t < n; t += nt) {
-    const uint64_t mine = src[t];
-    int rank = 0;
-    for (int j = 0; j < n; ++j) {
-      const uint64_t o = src[j];
-      rank += (o > mine || (o == mine && j < t)) ? 1 : 0;
-    }
-    dst[rank] = mine;
-  }
-  __syncthreads();
-}
-
-// Threshold T such that exactly `kth` of the non-empty keys are >= T (keys are unique).  If fewer
-// than `kth` non-empty keys exist, returns 1 (every non-empty key).  All threads return the same
-// value.  MSB-first radix select, 8 bits per pass, early exit once a whole bin is taken.
-__device__ uint64_t block_kth_largest(const uint64_t* keys, int64_t m, uint32_t kth, SelectShared& sh) {
-  const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
-  const int lane = tid & 63, wave = tid >> 6;
-  uint64_t prefix = 0;
-  uint32_t remaining = kth;
-  for (int shift = 56; shift >= 0; shift -= 8) {
-    if (tid < 256) sh.hist[tid] = 0;
-    __syncthreads();
-    for (int64_t i = tid; i < m; i += nt) {
-      const uint64_t k = keys[i];
-      if (k != kKeyEmpty && (shift == 56 || (k >> (shift + 8)) == prefix))
-        atomicAdd(&sh.hist[static_cast<uint32_t>(k >> shift) & 0xFFu], 1u);
-    }
-    __syncthreads();
-    uint32_t h = 0, sfx = 0;
-    if (tid < 256) {  // waves 0..3, all lanes active
-      h = sh.hist[tid];
-      sfx = h;
-      for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_down(sfx, off, kWave);
-        if (lane + off < 64) sfx += o;
-      }
-      if (lane == 0) sh.wave_tot[wave] = sfx;
-    }
-    __syncthreads();
-    if (tid < 256) {
-      uint32_t above = 0;
-      for (int w = wave + 1; w < 4; ++w) above += sh.wave_tot[w];
-      const uint32_t incl = sfx + above;  // keys (under this prefix) with digit >= tid
-      const uint32_t excl = incl - h;     // ... with digit > tid
-      if (tid == 0) sh.total = incl;
-      if (incl >= remaining && excl < remaining) {
-        sh.pick_digit = static_cast<uint32_t>(tid);
-        sh.pick_above = excl;
-        sh.pick_count = h;
-      }
-    }
-    __syncthreads();
-    if (sh.total < remaining) return 1ull;  // only possible on the first pass: fewer keys than kth
-    prefix = (prefix << 8) | sh.pick_digit;
-    remaining -= sh.pick_above;
-    const bool whole_bin = sh.pick_count == remaining;
-    __syncthreads();  // pick_* are rewritten by the next pass
-    if (whole_bin) return prefix << shift;
-  }
-  return prefix;
-}
 
 __device__ __forceinline__ float blend(const RerankParams& rp, float sim, float dewi, float ent) {
   // reference backends.py:461-465: (1-eta)*s and eta*dewi are rounded separately, then added.
@@ -277,12 +169,27 @@ __device__ int gather_top_candidates(const uint64_t* __restrict__ keys, int64_t 
 __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(
     const uint64_t* __restrict__ keys_all, int64_t keys_per_query, int sorted_lists, int n_candidates, int k,
     RerankParams rp, const float* __restrict__ dewi32, const float* __restrict__ ent32, int64_t id_offset,
-    int64_t* __restrict__ out_ids, float* __restrict__ out_scores, dewi_candidate* __restrict__ out_cand) {
+    int64_t* __restrict__ out_ids, float* __restrict__ out_scores, dewi_candidate* __restrict__ out_cand,
+    const uint32_t* __restrict__ counts) {
   __shared__ SelectShared sh;
   const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
   const int q = static_cast<int>(blockIdx.x);
   const uint64_t* keys = keys_all + static_cast<int64_t>(q) * keys_per_query;
-  const int n_sel = gather_top_candidates(keys, keys_per_query, sorted_lists, n_candidates, sh);
+  int64_t n_keys = keys_per_query;
+  if (counts != nullptr) {
+    const uint32_t have = counts[q];
+    if (static_cast<int64_t>(have) > keys_per_query) {
+      // the candidate buffer overflowed: this query was NOT answered; the caller re-runs it on the
+      // exact small-batch path (ids = -1 is the documented marker)
+      for (int j = tid; j < k; j += nt) {
+        out_ids[static_cast<int64_t>(q) * k + j] = -1;
+        out_scores[static_cast<int64_t>(q) * k + j] = __builtin_nanf("");
+      }
+      return;
+    }
+    n_keys = have;
+  }
+  const int n_sel = gather_top_candidates(keys, n_keys, sorted_lists, n_candidates, sh);
 
   if (out_cand != nullptr) {
     dewi_candidate* oc = out_cand + static_cast<int64_t>(q) * n_candidates;
@@ -362,7 +269,7 @@ __global__ __launch_bounds__(kSelectThreads) void merge_rerank_kernel(const dewi
 hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, int sorted_lists, int n_queries,
                                 int n_candidates, int k, const RerankParams& rp, const float* d_dewi32,
                                 const float* d_ent32, int64_t id_offset, int64_t* d_out_ids, float* d_out_scores,
-                                dewi_candidate* d_out_cand, hipStream_t stream) {
+                                dewi_candidate* d_out_cand, const uint32_t* d_counts, hipStream_t stream) {
   int threads = kSelectThreads;
   if (sorted_lists > 0) {
     threads = sorted_lists <= 64 ? 256 : kSelectThreads;
@@ -371,7 +278,7 @@ hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, 
   }
   hipLaunchKernelGGL(select_rerank_kernel, dim3(n_queries), dim3(threads), 0, stream, d_keys, keys_per_query,
                      sorted_lists, n_candidates, k, rp, d_dewi32, d_ent32, id_offset, d_out_ids, d_out_scores,
-                     d_out_cand);
+                     d_out_cand, d_counts);
   return hipGetLastError();
 }
 

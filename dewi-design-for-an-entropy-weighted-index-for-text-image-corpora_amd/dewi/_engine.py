@@ -177,6 +177,17 @@ class DeviceCorpus:
             ids, scores = self.search_device(q, k, eta, entropy_pref)
             ids_h = ids.cpu().numpy()
             scores_h = scores.cpu().numpy()
+            # The batched bf16 matrix-core path marks a query whose candidate buffer overflowed
+            # (adversarial corpora, e.g. tens of thousands of duplicates of a top document) with
+            # id -1: such queries are answered again by the exact small-batch kernels.
+            if ids_h.size and (ids_h[:, 0] < 0).any():
+                redo = np.nonzero(ids_h[:, 0] < 0)[0]
+                for s0 in range(0, len(redo), 8):
+                    sel = redo[s0:s0 + 8]
+                    sub = q[torch.from_numpy(sel).to(q.device)].contiguous()
+                    i2, s2 = self.search_device(sub, k, eta, entropy_pref)
+                    ids_h[sel] = i2.cpu().numpy()
+                    scores_h[sel] = s2.cpu().numpy()
         if self.id_offset:
             ids_h = ids_h + self.id_offset
         return ids_h, scores_h
@@ -296,5 +307,6 @@ def timing_read() -> Tuple[float, int]:
     return float(ms.value), int(n.value)
 
 
-def tuning(scan_blocks: int = 0, rows_per_iter: int = 0, nontemporal: int = -1) -> None:
-    nat.check(nat.load_library().dewi_tuning_set(int(scan_blocks), int(rows_per_iter), int(nontemporal)))
+def tuning(scan_blocks: int = 0, rows_per_iter: int = 0, nontemporal: int = -1, batched_mfma: int = 1) -> None:
+    nat.check(nat.load_library().dewi_tuning_set(int(scan_blocks), int(rows_per_iter), int(nontemporal),
+                                                 int(batched_mfma)))

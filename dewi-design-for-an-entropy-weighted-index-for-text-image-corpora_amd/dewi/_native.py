@@ -94,7 +94,7 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.dewi_timing_read.restype = i32
     lib.dewi_timing_read.argtypes = [c.POINTER(f64), c.POINTER(i32)]
     lib.dewi_tuning_set.restype = i32
-    lib.dewi_tuning_set.argtypes = [i32, i32, i32]
+    lib.dewi_tuning_set.argtypes = [i32, i32, i32, i32]
 
 
 def load_library(require_gpu: bool = True) -> ctypes.CDLL:

@@ -185,8 +185,9 @@ int dewi_score_f64(const void* d_S, int signals_are_f64, int64_t n, int64_t ld, 
 int dewi_timing_enable(int enable);
 int dewi_timing_read(double* out_mean_scan_ms, int* out_launches);
 
-/* Launch-shape overrides for tuning sweeps (0 = planner default). */
-int dewi_tuning_set(int scan_blocks, int rows_per_iter, int nontemporal);
+/* Launch-shape overrides for tuning sweeps (0 / -1 = planner default).  batched_mfma = 0 disables the
+ * matrix-core path of dewi_knn_rerank_bf16 (every batch then takes the small-batch scan kernels). */
+int dewi_tuning_set(int scan_blocks, int rows_per_iter, int nontemporal, int batched_mfma);
 
 #ifdef __cplusplus
 }

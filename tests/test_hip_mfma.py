@@ -1,0 +1,60 @@
+"""GPU parity tests of the batched bf16 matrix-core path (config C3's kernel) through the C ABI.
+
+The path is taken for >= 16 queries over a bf16 corpus of >= 64 K rows with dim % 128 == 0
+(<= 768).  Oracle and tolerances as in tests/test_hip_bf16.py (bf16-rounded inputs, 2e-5).
+The batched path and the small-batch scan kernels must also agree with EACH OTHER bit for bit on
+ids wherever both are decisive — checked directly.
+"""
+import numpy as np
+import pytest
+
+import dewi_oracle as orc
+from parity import check_batch
+
+pytestmark = pytest.mark.gpu
+TOL = dict(gap=2e-5, score_tol=2e-5, prepared=True, exact_gaps=False)
+
+
+def _corpus(n, dim, seed):
+    from dewi import _engine as eng
+    raw = orc.synth_corpus(n, dim, seed=seed)
+    cols = orc.synth_payload_columns(n, seed=seed)
+    cb = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"]).to_bf16()
+    dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    return cb, cb.emb.float().cpu().numpy(), dewi32, ent32
+
+
+@pytest.mark.parametrize("dim,n,b,k", [(768, 70_001, 256, 100), (768, 66_000, 40, 10), (512, 80_000, 300, 10),
+                                       (256, 70_000, 17, 100), (128, 131_072, 64, 10)])
+def test_mfma_batched_vs_oracle(dim, n, b, k):
+    cb, Eb, dewi32, ent32 = _corpus(n, dim, seed=dim + b)
+    Q = orc.synth_queries(b, dim, seed=b)
+    Qp = np.stack([orc.bf16_round(orc.prepare_query(q)) for q in Q])
+    ids, sc = cb.search(Q, k, 0.3, 0.1)
+    assert ids.min() >= 0 and not np.isnan(sc).any()
+    check_batch(Eb, Qp, dewi32, ent32, k, 0.3, 0.1, "cosine", ids, sc, max_excluded_frac=1.0, **TOL)
+    # same answers as the small-batch kernels (batches of 8 never take the matrix-core path)
+    ids_s = np.concatenate([cb.search(Q[i:i + 8], k, 0.3, 0.1)[0] for i in range(0, min(b, 32), 8)])
+    agree = np.mean(ids_s == ids[: ids_s.shape[0]])
+    assert agree > 0.98, agree          # the two paths sum in different orders: rare near-tie swaps only
+
+
+def test_mfma_overflow_falls_back_to_exact_path():
+    """40 000 exact duplicates of the query's best document overflow the candidate buffer of that
+    query (capacity 4*32*c); the marker (-1) triggers the exact small-batch kernels."""
+    from dewi import _engine as eng
+    import torch
+    n, dim, k = 100_000, 256, 10
+    raw = orc.synth_corpus(n, dim, seed=3)
+    raw[50_000:90_000] = raw[7]                       # rows 50000..89999 == row 7
+    cols = orc.synth_payload_columns(n, seed=3)
+    cb = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"]).to_bf16()
+    Q = orc.synth_queries(32, dim, seed=4)
+    Q[5] = raw[7]                                     # query 5 hits the duplicated document
+    q_dev = torch.from_numpy(Q).cuda()
+    ids_raw, _ = cb.search_device(q_dev, k, 0.0, 0.0)
+    ids_raw = ids_raw.cpu().numpy()
+    assert (ids_raw[5] == -1).all() and (np.delete(ids_raw, 5, axis=0) >= 0).all()
+    ids, sc = cb.search(Q, k, 0.0, 0.0)               # blocking API repairs it
+    assert ids[5].tolist() == [7] + list(range(50_000, 50_009))      # ties: lower rows first
+    assert np.allclose(sc[5], 1.0, atol=1e-2)
