@@ -177,7 +177,7 @@ int knn_rerank_impl(const void* d_E, int elem_type, int64_t n_rows, int dim, con
   char* ws = static_cast<char*>(d_ws);
   if (elem_type == 1 && g_tuning.mfma != 0 && dewi::mfma_path_supported(n_rows, dim, n_queries, c, space)) {
     // many queries over a bf16 corpus: matrix-core path, one corpus pass per 256 queries
-    const dewi::MfmaLayout M = dewi::plan_mfma(n_rows, dim, n_queries, c);
+    const dewi::MfmaLayout M = dewi::plan_mfma(n_rows, dim, n_queries, c, dev.cus);
     if (!d_ws || ws_bytes < M.total) return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, M.total);
     hipError_t e;
     {
@@ -186,9 +186,19 @@ int knn_rerank_impl(const void* d_E, int elem_type, int64_t n_rows, int dim, con
                                  stream);
     }
     if (e != hipSuccess) return hip_fail(e, "mfma scan launch");
-    e = dewi::launch_select_rerank(reinterpret_cast<const uint64_t*>(ws + M.cand_off), M.capq, 0, n_queries, c, k,
-                                   make_rerank(eta, pref), d_dewi32, d_ent32, 0, d_out_ids, d_out_scores, nullptr,
-                                   reinterpret_cast<const uint32_t*>(ws + M.cnt_off), stream);
+    // one select launch per group of 256 queries (each group has its own segments)
+    const dewi::RerankParams rp = make_rerank(eta, pref);
+    for (int g = 0; g < M.groups; ++g) {
+      const int q0 = g * 256;
+      const int nq = n_queries - q0 < 256 ? n_queries - q0 : 256;
+      const dewi::SegmentLayout seg{M.n_seg, M.seg_cap, 1, static_cast<int64_t>(256) * M.seg_cap, 256};
+      const uint64_t* keys = reinterpret_cast<const uint64_t*>(ws + M.cand_off) +
+                             static_cast<int64_t>(g) * M.n_seg * 256 * M.seg_cap;
+      const uint32_t* counts = reinterpret_cast<const uint32_t*>(ws + M.cnt_off) + static_cast<int64_t>(g) * M.n_seg * 256;
+      e = dewi::launch_select_rerank(keys, 0, 0, nq, c, k, rp, d_dewi32, d_ent32, 0, d_out_ids + static_cast<int64_t>(q0) * k,
+                                     d_out_scores + static_cast<int64_t>(q0) * k, nullptr, counts, seg, stream);
+      if (e != hipSuccess) break;
+    }
     if (e != hipSuccess) return hip_fail(e, "select_rerank launch");
     return DEWI_OK;
   }
@@ -199,7 +209,7 @@ int knn_rerank_impl(const void* d_E, int elem_type, int64_t n_rows, int dim, con
   const dewi::RerankParams rp = make_rerank(eta, pref);
   hipError_t e = dewi::launch_select_rerank(reinterpret_cast<const uint64_t*>(ws + L.keys_off), L.plan.keys_per_query,
                                             L.plan.slots == 1 ? L.plan.n_lists : 0, n_queries, c, k, rp, d_dewi32, d_ent32, 0, d_out_ids, d_out_scores, nullptr,
-                                            nullptr, stream);
+                                            nullptr, dewi::SegmentLayout{}, stream);
   if (e != hipSuccess) return hip_fail(e, "select_rerank launch");
   return DEWI_OK;
 }
@@ -255,7 +265,7 @@ size_t dewi_knn_workspace_bytes(int64_t n_rows, int dim, int n_queries, int n_ca
   const size_t b = layout_knn(n_rows, dim, 2, n_queries, n_candidates, dev.cus).total;
   if (b > a) a = b;
   if (dewi::mfma_path_supported(n_rows, dim, n_queries, n_candidates, DEWI_SPACE_COSINE)) {
-    const size_t m = dewi::plan_mfma(n_rows, dim, n_queries, n_candidates).total;
+    const size_t m = dewi::plan_mfma(n_rows, dim, n_queries, n_candidates, dev.cus).total;
     if (m > a) a = m;
   }
   return a;  // valid for either element type and either bf16 path
@@ -317,7 +327,7 @@ int dewi_knn_finish(const void* d_workspace, size_t workspace_bytes, int elem_ty
                                             sorted, n_queries, n_candidates, records ? 0 : k,
                                             make_rerank(records ? 0.0 : eta, records ? 0.0 : entropy_pref), d_dewi32,
                                             d_ent32, id_offset, d_out_ids, d_out_scores, d_out_cand, nullptr,
-                                            static_cast<hipStream_t>(stream_));
+                                            dewi::SegmentLayout{}, static_cast<hipStream_t>(stream_));
   return e == hipSuccess ? DEWI_OK : hip_fail(e, "select launch");
 }
 
@@ -359,7 +369,7 @@ int dewi_knn_candidates(const void* d_E, int elem_type, int64_t n_rows, int dim,
   hipError_t e = dewi::launch_select_rerank(reinterpret_cast<const uint64_t*>(ws + L.keys_off), L.plan.keys_per_query,
                                             (L.plan.slots == 1 && c_local == n_candidates) ? L.plan.n_lists : 0,
                                             n_queries, n_candidates, 0, rp, d_dewi32, d_ent32, id_offset, nullptr,
-                                            nullptr, d_out, nullptr, stream);
+                                            nullptr, d_out, nullptr, dewi::SegmentLayout{}, stream);
   if (e != hipSuccess) return hip_fail(e, "select (candidates) launch");
   return DEWI_OK;
 }

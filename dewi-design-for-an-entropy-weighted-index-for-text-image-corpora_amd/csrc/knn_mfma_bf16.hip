@@ -9,25 +9,29 @@
 // Roofline: co-limited.  Algorithmic bytes per pass = n_rows*dim*2 (HBM, read once); flops =
 // 2*256*n_rows*dim (393 GFLOP at C3) -> 256 flop/B against a ~310 flop/B machine balance.
 //
-// Structure (one 4-wave workgroup per CU — one wave per SIMD, each with the whole 512-register
-// file — persistent over 32-document tiles):
-//  * QUERIES LIVE IN REGISTERS.  Wave w owns queries 64w..64w+63 for the whole kernel: their B
-//    fragments (2 x dim/16 x 4 VGPRs = 384 at dim 768) are loaded once.  No query traffic, no LDS
-//    for Q, and every A fragment read from LDS feeds two MFMAs.
+// Structure (one 8-wave workgroup per CU, two waves per SIMD, persistent over 32-document tiles):
+//  * QUERIES LIVE IN REGISTERS.  Wave w owns queries 32w..32w+31 for the whole kernel: their B
+//    fragments (dim/16 x 4 VGPRs = 192 of the 256 available at dim 768) are loaded once.  No query
+//    traffic, no LDS for Q.
 //  * DOCUMENT TILES GO THROUGH LDS BY DMA.  A tile (32 rows x dim bf16 = 48 KiB) is copied
 //    global->LDS with global_load_lds_dwordx4 (1 KiB per wave-instruction, no VGPR staging),
 //    double-buffered: tile i+1 is in flight while tile i is multiplied (counted vmcnt, raw
-//    s_barrier).  All 4 waves read the same tile (A operand) with ds_read_b128.
+//    s_barrier).  All 8 waves read the same tile (A operand) with ds_read_b128.
 //  * BANK CONFLICTS: rows are 1536 B apart (= 0 mod 256 B), so an A-fragment read (16 lanes = 16
 //    rows, same 16-byte column unit) would be 16-way conflicted.  The LDS image is linear (DMA
 //    writes base + lane*16) and the SOURCE address is permuted instead: unit c of row r is stored
 //    at unit (c & ~15) | ((c & 15) ^ (r & 15)); reads apply the same XOR -> conflict-free.
-//  * EPILOGUE.  D[doc][query]: lane l holds query l&31 and 16 documents.  Filter mode: a score
-//    passes if it is not below the query's threshold (a lower bound of its final c-th best score,
-//    from a strided 1/32 sample of the corpus scanned in dense mode first); survivors are appended
-//    to the query's candidate buffer with one global atomic each (~32c per query over the pass).
-//    If a buffer overflows (only for adversarial corpora, e.g. tens of thousands of exact
-//    duplicates of a top document) the count keeps growing and the finish kernel flags the query.
+//  * EPILOGUE.  D[doc][query]: lane l holds query l&31 (+32) and 16 documents.  Filter mode: a
+//    score passes if it is not below the query's threshold (a lower bound of its final c-th best
+//    score, from a strided 1/32 sample of the corpus scanned in dense mode first).  Survivors
+//    (~32c per query over the whole pass) go to a half-segment PRIVATE to one lane: a query
+//    belongs to one wave and to two of its lanes, so the slot counter is a register and the record
+//    a fire-and-forget global store — no atomics, nothing that drains the DMA queue.  (Appending
+//    with returning global atomics: 1.85 ms per pass; LDS counters + per-element predication:
+//    0.54 ms, 1/3 of it epilogue.)  One v_cmp per accumulator register doubles as the wave-wide
+//    ballot, so registers without survivors cost a compare and a scalar branch.  If a half-segment
+//    overflows (only for adversarial corpora, e.g. tens of thousands of exact duplicates of a top
+//    document) its count keeps growing and the finish kernel flags the query.
 #include "select_common.hpp"
 
 namespace dewi {
@@ -36,10 +40,19 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4m __attribute__((ext_vector_type(4)));
 
-constexpr int kMfmaThreads = 256;     // 4 waves, one per SIMD: each owns 64 queries and the whole 512-register file
+#ifndef DEWI_MFMA_QB
+#define DEWI_MFMA_QB 1   // 32-query blocks per wave: 1 -> 8 waves (two per SIMD, 256 registers each), 2 -> 4 waves.
+                         // Measured (1M x 768, 256 queries): 8 waves 379 us, 4 waves 492 us per pass — with one wave
+                         // per SIMD nothing covers its DMA issue, epilogue and barrier time.
+#endif
+constexpr int kQB = DEWI_MFMA_QB;
+constexpr int kMfmaThreads = 64 * (8 / kQB);
 constexpr int kTileRows = 32;
-constexpr int kQueriesPerPass = 256;  // 4 waves x 64
+constexpr int kQueriesPerPass = 256;  // 8 waves x 32 (or 4 x 64)
 constexpr int kSampleStride = 32;     // every 32nd tile is a sample tile
+#ifndef DEWI_MFMA_ABLATE
+#define DEWI_MFMA_ABLATE 0   // timing experiments only: 1 no epilogue, 2 no DMA after the first tile, 3 no MFMA
+#endif
 
 using GlobalPtr = const void __attribute__((address_space(1)))*;
 using LdsPtr = void __attribute__((address_space(3)))*;
@@ -75,10 +88,12 @@ __global__ __launch_bounds__(kWave) void prepare_queries_bf16(const float* __res
 // KS = dim / 16 MFMA k-steps (dim % 128 == 0, dim <= 768).
 // Tiles handled by this launch: t = first_tile + i * tile_stride, i in [0, n_tiles).
 template <int KS, bool DENSE>
-__global__ __launch_bounds__(kMfmaThreads, 1) void mfma_scan_bf16(
+__global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
     const uint16_t* __restrict__ E, int64_t n_rows, const uint16_t* __restrict__ Qb, int64_t n_tiles,
     int64_t tile_stride, const float* __restrict__ thr, uint64_t* __restrict__ out, int64_t out_stride,
     uint32_t* __restrict__ cnt) {
+  // DENSE: out[q * out_stride + sample position] for every document of the (strided) tiles.
+  // filter: raw records out[((2*blockIdx.x + h) * 256 + q) * out_stride + slot], cnt[(2*blockIdx.x + h) * 256 + q].
 #if defined(__HIP_DEVICE_COMPILE__)  // the body holds gfx950 inline asm: the host pass only needs the launch stub
   constexpr int DIM = KS * 16;
   constexpr int UPR = DIM / 8;                     // 16-byte units per row
@@ -95,27 +110,26 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void mfma_scan_bf16(
 
   // ---- query fragments (B operand): two 32-query blocks per wave; lane holds
   //      Qb[64*wave + 32*b + r][16 s + 8 h .. +7]
-  bf16x8 qf[2][KS];
+  bf16x8 qf[kQB][KS];
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const bf16x8* qp = reinterpret_cast<const bf16x8*>(Qb + static_cast<int64_t>(64 * wave + 32 * b + r) * DIM + 8 * h);
+  for (int b = 0; b < kQB; ++b) {
+    const bf16x8* qp = reinterpret_cast<const bf16x8*>(Qb + static_cast<int64_t>(32 * kQB * wave + 32 * b + r) * DIM + 8 * h);
 #pragma unroll
     for (int s = 0; s < KS; ++s) qf[b][s] = qp[2 * s];
   }
-  float thr_l[2] = {-__builtin_inff(), -__builtin_inff()};
-  if constexpr (!DENSE) {
-    thr_l[0] = thr[64 * wave + r];
-    thr_l[1] = thr[64 * wave + 32 + r];
-  }
+  float thr_l[kQB];
+#pragma unroll
+  for (int b = 0; b < kQB; ++b) thr_l[b] = DENSE ? -__builtin_inff() : thr[32 * kQB * wave + 32 * b + r];
   // Pin the compiler's waits for these loads HERE, before any DMA is in flight: their first real use
   // is inside the tile loop, and a compiler-inserted vmcnt(0) there would drain the prefetch of the
   // next tile on every iteration.
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
-    asm volatile("" ::"v"(qf[0][s]));
-    asm volatile("" ::"v"(qf[1][s]));
+#pragma unroll
+    for (int b = 0; b < kQB; ++b) asm volatile("" ::"v"(qf[b][s]));
   }
-  asm volatile("" ::"v"(thr_l[0]), "v"(thr_l[1]));
+#pragma unroll
+  for (int b = 0; b < kQB; ++b) asm volatile("" ::"v"(thr_l[b]));
 
   // ---- per-lane DMA source offsets (bytes from the tile's first row), one per piece this wave moves
   uint32_t voff[PPW];
@@ -129,9 +143,11 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void mfma_scan_bf16(
   }
   // ---- per-lane A-fragment read offsets inside a tile buffer
   const int z = (r & 15) ^ h;
-  uint32_t a_off[8];
+  uint32_t a_addr[8];  // LDS byte addresses for buffer 0; flipped to the other buffer in place every tile
 #pragma unroll
-  for (int j = 0; j < 8; ++j) a_off[j] = static_cast<uint32_t>(r * UPR * 16 + 16 * ((2 * j) ^ z));
+  for (int j = 0; j < 8; ++j)
+    a_addr[j] = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((LdsPtr)(lds))) +
+                static_cast<uint32_t>(r * UPR * 16 + 16 * ((2 * j) ^ z));
 
   // A tile is fetched through a buffer descriptor whose base is the tile's first row and whose
   // size is the tile's valid bytes: rows past the end of the corpus (partial last tile) read as
@@ -139,49 +155,63 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void mfma_scan_bf16(
   // register per piece.
   const char* Eb = reinterpret_cast<const char*>(E);
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  auto issue_tile = [&](int64_t tile_index, int buf) {
+  auto tile_rsrc = [&](int64_t tile_index) {
     const int64_t row0 = tile_index * kTileRows;
     const int64_t left = n_rows - row0;
     const int valid_rows = left < kTileRows ? static_cast<int>(left) : kTileRows;
-    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(Eb + row0 * (DIM * 2)), 0, valid_rows * (DIM * 2), 0x00020000);
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      char* l = lds + buf * TILE_BYTES + (i * NW + wave_u) * 1024;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)(l), 16, voff[i], 0, 0, 0);
-    }
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Eb + row0 * (DIM * 2)), 0, valid_rows * (DIM * 2),
+                                             0x00020000);
   };
+  auto issue_piece = [&](__amdgpu_buffer_rsrc_t rsrc, int buf, int i) {
+    char* l = lds + buf * TILE_BYTES + (i * NW + wave_u) * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)(l), 16, voff[i], 0, 0, 0);
+  };
+
+  // ---- survivor segments.  Queries belong to exactly one wave and to exactly two of its lanes
+  // (l and l+32, which hold different documents), so each LANE owns a private half-segment per
+  // query block and its slot counter is a plain register: no atomics of any kind.
+  // segment index = 2*blockIdx.x + h; keys at out[(segment*256 + q) * out_stride + slot].
+  // slot[b] = index into `out` of the next free record of this lane's half-segment (32-bit: the
+  // whole candidate area is far below 2^32 records).
+  uint32_t slot[kQB];
+#pragma unroll
+  for (int b = 0; b < kQB; ++b)
+    slot[b] = ((static_cast<uint32_t>(blockIdx.x) * 2 + h) * kQueriesPerPass + (32 * kQB * wave + 32 * b + r)) *
+              static_cast<uint32_t>(out_stride);
 
   const int64_t first = static_cast<int64_t>(blockIdx.x);
   const int64_t step = static_cast<int64_t>(gridDim.x);
-  if (first < n_tiles) issue_tile(first * tile_stride, 0);
+  if (first < n_tiles) {
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(first * tile_stride);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) issue_piece(rs, 0, i);
+  }
   int buf = 0;
   for (int64_t i = first; i < n_tiles; i += step) {
     const int64_t tile = i * tile_stride;
-    const bool has_next = i + step < n_tiles;
-    if (has_next) issue_tile((i + step) * tile_stride, buf ^ 1);
-    // wait for THIS tile's pieces (the newer PPW pieces of the next tile may stay in flight)
-    if (has_next) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();                   // every wave's pieces of this tile have landed
+    const bool has_next = (i + step < n_tiles) && DEWI_MFMA_ABLATE != 2;
+    // This tile's pieces were issued during the previous tile's matrix block (or in the prologue);
+    // nothing younger is in flight except that iteration's few survivor stores.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // (a) every wave's pieces of this tile have landed
+                                    // (b) every wave has finished reading the OTHER buffer, which
+                                    //     the DMA below starts refilling
     asm volatile("" ::: "memory");
+    const __amdgpu_buffer_rsrc_t next_rsrc = tile_rsrc(has_next ? (i + step) * tile_stride : tile);
 
-    f32x16 acc[2];
+    f32x16 acc[kQB];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[0][j] = acc[1][j] = 0.f;
+    for (int b = 0; b < kQB; ++b) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[b][j] = 0.f;
+    }
     // A fragments are read two k-steps ahead of the MFMAs that consume them (each feeds two MFMAs,
     // 64 cycles of matrix work per read).  hipcc sinks plain LDS loads back next to their use at this
     // register pressure, so the reads and their counted waits are inline asm: LDS returns data in
     // order, hence before step s may start at most the two younger reads (s+1, s+2) may be pending.
     // The wait statement takes the fragment as an in/out operand so that the MFMAs cannot be
-    // scheduled above it.  No other LGKM operation is issued inside this block.
-    const uint32_t tile_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((LdsPtr)(lds))) + buf * TILE_BYTES;
-    uint32_t a_addr[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) a_addr[j] = tile_lds + a_off[j];
+    // scheduled above it.  No other LGKM operation is issued inside this block.  The next tile's DMA
+    // pieces are issued one per KS/PPW k-steps, in the shadow of the MFMAs.
     u32x4m a0, a1, a2;
     asm volatile("ds_read_b128 %0, %1" : "=v"(a0) : "v"(a_addr[0]));
     asm volatile("ds_read_b128 %0, %1" : "=v"(a1) : "v"(a_addr[1]));
@@ -196,37 +226,71 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void mfma_scan_bf16(
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0));
       }
       const bf16x8 a = __builtin_bit_cast(bf16x8, a0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[0][s], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[1][s], acc[1], 0, 0, 0);
+      if (DEWI_MFMA_ABLATE != 3) {
+#pragma unroll
+        for (int b = 0; b < kQB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[b][s], acc[b], 0, 0, 0);
+      } else {
+        asm volatile("" ::"v"(a));
+      }
+      if (s % (KS / PPW) == 1 && has_next) issue_piece(next_rsrc, buf ^ 1, s / (KS / PPW));
       a0 = a1;
       a1 = a2;
     }
 
     // ---- epilogue: D[doc = (j&3) + 8*(j>>2) + 4*h][query = 64*wave + 32*b + r]
     const int64_t row0 = tile * kTileRows;
+    const int doc0 = static_cast<int>(row0) + 4 * h;           // n_rows < 2^32 and row0 < n_rows
+    if (row0 + kTileRows > n_rows) {                           // partial last tile: padding rows never pass
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int q = 64 * wave + 32 * b + r;
+      for (int b = 0; b < kQB; ++b) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int local = (j & 3) + 8 * (j >> 2) + 4 * h;
-        const int64_t doc = row0 + local;
-        const float sc = acc[b][j];
-        if constexpr (DENSE) {
+        for (int j = 0; j < 16; ++j)
+          if (row0 + (j & 3) + 8 * (j >> 2) + 4 * h >= n_rows) acc[b][j] = -__builtin_inff();
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < kQB; ++b) {
+      if (DEWI_MFMA_ABLATE == 1) {
+        asm volatile("" ::"v"(acc[b]));
+      } else if constexpr (DENSE) {
+        const int q = 32 * kQB * wave + 32 * b + r;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int local = (j & 3) + 8 * (j >> 2) + 4 * h;
           out[static_cast<int64_t>(q) * out_stride + i * kTileRows + local] =
-              doc < n_rows ? make_key(sc, static_cast<uint32_t>(doc)) : kKeyEmpty;
-        } else {
-          if (doc < n_rows && !(sc < thr_l[b])) {    // NaN passes (NumPy ranks NaN first)
-            const uint32_t slot = atomicAdd(&cnt[q], 1u);
-            if (static_cast<int64_t>(slot) < out_stride)
-              out[static_cast<int64_t>(q) * out_stride + slot] = make_key(sc, static_cast<uint32_t>(doc));
+              row0 + local < n_rows ? make_key(acc[b][j], static_cast<uint32_t>(row0 + local)) : kKeyEmpty;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          // one v_cmp per accumulator register; its result IS the wave-wide ballot, so registers in
+          // which no lane passes (most of them) cost one compare and one scalar branch
+          const bool pass = !(acc[b][j] < thr_l[b]);           // NaN passes (NumPy ranks NaN first)
+          if (__builtin_amdgcn_ballot_w64(pass) != 0ull) {
+            if (pass) {
+              const uint32_t seg_q = (static_cast<uint32_t>(blockIdx.x) * 2 + h) * kQueriesPerPass + (32 * kQB * wave + 32 * b + r);
+              if (slot[b] - seg_q * static_cast<uint32_t>(out_stride) < static_cast<uint32_t>(out_stride)) {
+                // raw record: high word = document row, low word = fp32 score bits (the finish kernel
+                // builds the ordered key)
+                out[slot[b]] = (static_cast<uint64_t>(static_cast<uint32_t>(doc0 + (j & 3) + 8 * (j >> 2))) << 32) |
+                               __float_as_uint(acc[b][j]);
+              }
+              ++slot[b];
+            }
           }
         }
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                   // all waves finished reading buf before it is refilled
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a_addr[j] = buf ? a_addr[j] - TILE_BYTES : a_addr[j] + TILE_BYTES;
     buf ^= 1;
+  }
+  if constexpr (!DENSE) {
+#pragma unroll
+    for (int b = 0; b < kQB; ++b) {
+      const uint32_t seg_q = (static_cast<uint32_t>(blockIdx.x) * 2 + h) * kQueriesPerPass + (32 * kQB * wave + 32 * b + r);
+      cnt[seg_q] = slot[b] - seg_q * static_cast<uint32_t>(out_stride);
+    }
   }
 #endif
 }
@@ -238,7 +302,7 @@ __global__ __launch_bounds__(kSelectThreads) void sample_threshold_kernel(const 
                                                                           int n_candidates, float* __restrict__ thr) {
   __shared__ SelectShared sh;
   const int q = static_cast<int>(blockIdx.x);
-  const uint64_t key = block_kth_largest(dense + static_cast<int64_t>(q) * stride, n_sample,
+  const uint64_t key = block_kth_largest(ArrayKeys{dense + static_cast<int64_t>(q) * stride, n_sample},
                                          static_cast<uint32_t>(n_candidates), sh);
   if (threadIdx.x == 0) thr[q] = key <= 1ull ? -__builtin_inff() : key_score(key);
 }
@@ -252,7 +316,7 @@ bool mfma_path_supported(int64_t n_rows, int dim, int n_queries, int n_candidate
          n_rows / (kTileRows * kSampleStride) * kTileRows >= 4 * static_cast<int64_t>(n_candidates);
 }
 
-MfmaLayout plan_mfma(int64_t n_rows, int dim, int n_queries, int n_candidates) {
+MfmaLayout plan_mfma(int64_t n_rows, int dim, int n_queries, int n_candidates, int compute_units) {
   MfmaLayout m{};
   auto up = [](size_t v) { return (v + 255) / 256 * 256; };
   m.groups = (n_queries + kQueriesPerPass - 1) / kQueriesPerPass;
@@ -260,15 +324,19 @@ MfmaLayout plan_mfma(int64_t n_rows, int dim, int n_queries, int n_candidates) {
   m.n_tiles = (n_rows + kTileRows - 1) / kTileRows;
   m.n_sample_tiles = (m.n_tiles + kSampleStride - 1) / kSampleStride;
   m.sample_stride = static_cast<int64_t>(m.n_sample_tiles) * kTileRows;
-  // expected survivors per query ~ n_rows * c / n_sample = 32 c; 4x head-room, at least 4096
-  int64_t cap = 4ll * kSampleStride * n_candidates;
-  m.capq = cap < 4096 ? 4096 : cap;
+  // Filter pass: one workgroup per CU; every (workgroup, lane half, query) has a private half-segment.
+  // Expected survivors per query ~ n_rows * c / n_sample = 32 c, spread evenly over the half-segments;
+  // 4x head-room, at least 32 records.
+  m.n_blocks = m.n_tiles < compute_units ? static_cast<int>(m.n_tiles) : compute_units;
+  m.n_seg = 2 * m.n_blocks;
+  int64_t cap = (4ll * kSampleStride * n_candidates + m.n_seg - 1) / m.n_seg;
+  m.seg_cap = static_cast<int>(cap < 32 ? 32 : cap);
   size_t off = 0;
   m.qb_off = off;      off += up(static_cast<size_t>(m.q_pad) * dim * 2);
   m.thr_off = off;     off += up(static_cast<size_t>(m.q_pad) * 4);
-  m.cnt_off = off;     off += up(static_cast<size_t>(m.q_pad) * 4);
+  m.cnt_off = off;     off += up(static_cast<size_t>(m.groups) * m.n_seg * kQueriesPerPass * 4);
   m.dense_off = off;   off += up(static_cast<size_t>(kQueriesPerPass) * m.sample_stride * 8);
-  m.cand_off = off;    off += up(static_cast<size_t>(m.q_pad) * m.capq * 8);
+  m.cand_off = off;    off += up(static_cast<size_t>(m.groups) * m.n_seg * kQueriesPerPass * m.seg_cap * 8);
   m.total = off;
   return m;
 }
@@ -296,8 +364,8 @@ static hipError_t run_mfma_dim(const MfmaLayout& m, const uint16_t* E, int64_t n
   for (int g = 0; g < m.groups; ++g) {
     const uint16_t* qg = qb + static_cast<int64_t>(g) * kQueriesPerPass * DIM;
     float* tg = thr + g * kQueriesPerPass;
-    uint32_t* cg = cnt + g * kQueriesPerPass;
-    uint64_t* og = cand + static_cast<int64_t>(g) * kQueriesPerPass * m.capq;
+    uint32_t* cg = cnt + static_cast<int64_t>(g) * m.n_seg * kQueriesPerPass;
+    uint64_t* og = cand + static_cast<int64_t>(g) * m.n_seg * kQueriesPerPass * m.seg_cap;
     // 1. dense scores of the strided sample
     const int sample_blocks = m.n_sample_tiles < compute_units ? static_cast<int>(m.n_sample_tiles) : compute_units;
     hipLaunchKernelGGL((mfma_scan_bf16<KS, true>), dim3(sample_blocks), dim3(kMfmaThreads), lds_bytes, stream, E, n_rows,
@@ -306,10 +374,10 @@ static hipError_t run_mfma_dim(const MfmaLayout& m, const uint16_t* E, int64_t n
     // 2. per-query threshold
     hipLaunchKernelGGL(sample_threshold_kernel, dim3(kQueriesPerPass), dim3(kSelectThreads), 0, stream, dense,
                        m.sample_stride, m.sample_stride, n_candidates, tg);
-    // 3. full pass with the filter
-    const int blocks = m.n_tiles < compute_units ? static_cast<int>(m.n_tiles) : compute_units;
-    hipLaunchKernelGGL((mfma_scan_bf16<KS, false>), dim3(blocks), dim3(kMfmaThreads), lds_bytes, stream, E, n_rows, qg,
-                       m.n_tiles, static_cast<int64_t>(1), static_cast<const float*>(tg), og, m.capq, cg);
+    // 3. full pass with the filter: n_blocks workgroups, each writing its own half-segments and counts
+    hipLaunchKernelGGL((mfma_scan_bf16<KS, false>), dim3(m.n_blocks), dim3(kMfmaThreads), lds_bytes, stream, E, n_rows, qg,
+                       m.n_tiles, static_cast<int64_t>(1), static_cast<const float*>(tg), og,
+                       static_cast<int64_t>(m.seg_cap), cg);
   }
   return hipGetLastError();
 }
@@ -317,8 +385,6 @@ static hipError_t run_mfma_dim(const MfmaLayout& m, const uint16_t* E, int64_t n
 hipError_t launch_mfma_bf16(const MfmaLayout& m, const uint16_t* d_E, int64_t n_rows, int dim, const float* d_Q,
                             int n_queries, int n_candidates, int space, char* ws, int compute_units,
                             hipStream_t stream) {
-  hipError_t e = hipMemsetAsync(ws + m.cnt_off, 0, static_cast<size_t>(m.q_pad) * 4, stream);
-  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(prepare_queries_bf16, dim3(m.q_pad), dim3(kWave), 0, stream, d_Q,
                      reinterpret_cast<uint16_t*>(ws + m.qb_off), n_queries, dim, space);
   switch (dim / 16) {

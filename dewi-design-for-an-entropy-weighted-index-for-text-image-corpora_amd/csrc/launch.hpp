@@ -68,12 +68,14 @@ struct MfmaLayout {
   int64_t n_tiles;         // 32-row tiles
   int64_t n_sample_tiles;  // every 32nd tile
   int64_t sample_stride;   // dense sample keys per query (n_sample_tiles * 32)
-  int64_t capq;            // candidate-buffer capacity per query
+  int n_blocks;            // workgroups of the filter pass
+  int n_seg;               // candidate half-segments per query (2 per workgroup)
+  int seg_cap;             // records per half-segment
   size_t qb_off, thr_off, cnt_off, dense_off, cand_off, total;
 };
 bool mfma_path_supported(int64_t n_rows, int dim, int n_queries, int n_candidates, int space);
-MfmaLayout plan_mfma(int64_t n_rows, int dim, int n_queries, int n_candidates);
-// Fills cand keys [q_pad][capq] and counts [q_pad] in the workspace for every query.
+MfmaLayout plan_mfma(int64_t n_rows, int dim, int n_queries, int n_candidates, int compute_units);
+// Fills cand keys [groups][n_seg][256][seg_cap] and counts [groups][n_seg][256] in the workspace.
 hipError_t launch_mfma_bf16(const MfmaLayout& m, const uint16_t* d_E, int64_t n_rows, int dim, const float* d_Q,
                             int n_queries, int n_candidates, int space, char* ws, int compute_units,
                             hipStream_t stream);
@@ -88,12 +90,21 @@ struct RerankParams {
 // keys [n_queries][keys_per_query] -> top n_candidates by key -> either final (ids, scores) or
 // sorted candidate records.
 // sorted_lists > 0: the keys are `sorted_lists` lists of n_candidates keys, each sorted descending.
-// d_counts (may be NULL): number of valid keys per query (<= keys_per_query); a count ABOVE
-// keys_per_query marks an overflowed candidate buffer: that query's ids are set to -1, scores to NaN.
+// d_counts (may be NULL): the keys are per-workgroup SEGMENTS (batched matrix-core scan): segment s of
+// query q holds min(d_counts[s*count_stride + q], cap) keys at d_keys + s*seg_stride + q*cap; a count
+// above `cap` marks an overflowed buffer: that query's ids are set to -1, scores to NaN.
+struct SegmentLayout {
+  int n_seg;
+  int cap;
+  int raw;               // 1: entries are raw records (row << 32 | fp32 score bits), not ordered keys
+  int64_t seg_stride;    // keys between consecutive segments (= queries_per_pass * cap)
+  int64_t count_stride;  // counts between consecutive segments (= queries_per_pass)
+};
 hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, int sorted_lists, int n_queries,
                                 int n_candidates, int k, const RerankParams& rp, const float* d_dewi32, const float* d_ent32,
                                 int64_t id_offset, int64_t* d_out_ids, float* d_out_scores,
-                                dewi_candidate* d_out_cand, const uint32_t* d_counts, hipStream_t stream);
+                                dewi_candidate* d_out_cand, const uint32_t* d_counts, const SegmentLayout& seg,
+                                hipStream_t stream);
 hipError_t launch_merge_rerank(const dewi_candidate* d_lists, int n_lists, int n_queries, int list_len,
                                int n_candidates, int k, const RerankParams& rp, int64_t* d_out_ids,
                                float* d_out_scores, hipStream_t stream);

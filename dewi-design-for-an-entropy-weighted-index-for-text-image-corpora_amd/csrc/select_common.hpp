@@ -62,10 +62,53 @@ __device__ inline void rank_sort_desc(const uint64_t* src, uint64_t* dst, int n)
   __syncthreads();
 }
 
+// Where a query's candidate keys live.  ArrayKeys: one dense array (kKeyEmpty entries are skipped).
+// SegmentKeys: the batched matrix-core scan's output — `n_seg` per-workgroup segments of capacity
+// `cap`, of which only the first count[seg] entries were written.
+struct ArrayKeys {
+  const uint64_t* p;
+  int64_t n;
+  // f(key) for every non-empty key, the work split over the nt threads of the workgroup
+  template <class F>
+  __device__ __forceinline__ void for_each(int tid, int nt, F f) const {
+    for (int64_t i = tid; i < n; i += nt) {
+      const uint64_t k = p[i];
+      if (k != kKeyEmpty) f(k);
+    }
+  }
+};
+struct SegmentKeys {
+  const uint64_t* p;       // this query's first segment
+  const uint32_t* count;   // this query's first count
+  int64_t seg_stride;      // keys between consecutive segments of the same query
+  int64_t count_stride;    // counts between consecutive segments of the same query
+  int n_seg, cap;
+  bool raw;                // entries are (row << 32 | fp32 score bits) records: build the key on read
+  // Threads take (segment, lane-in-group) pairs: 4 consecutive threads share a segment, so the few
+  // valid records at the head of each of the hundreds of segments are read without touching the
+  // empty tails.
+  template <class F>
+  __device__ __forceinline__ void for_each(int tid, int nt, F f) const {
+    constexpr int kGroup = 4;
+    const int sub = tid % kGroup;
+    for (int seg = tid / kGroup; seg < n_seg; seg += nt / kGroup) {
+      uint32_t c = count[seg * count_stride];
+      c = c < static_cast<uint32_t>(cap) ? c : static_cast<uint32_t>(cap);
+      const uint64_t* sp = p + seg * seg_stride;
+      for (uint32_t j = sub; j < c; j += kGroup) {
+        const uint64_t v = sp[j];
+        const uint64_t k = raw ? make_key(__uint_as_float(static_cast<uint32_t>(v)), static_cast<uint32_t>(v >> 32)) : v;
+        if (k != kKeyEmpty) f(k);
+      }
+    }
+  }
+};
+
 // Threshold T such that exactly `kth` of the non-empty keys are >= T (keys are unique).  If fewer
 // than `kth` non-empty keys exist, returns 1 (every non-empty key).  All threads return the same
 // value.  MSB-first radix select, 8 bits per pass, early exit once a whole bin is taken.
-__device__ inline uint64_t block_kth_largest(const uint64_t* keys, int64_t m, uint32_t kth, SelectShared& sh) {
+template <class Keys>
+__device__ inline uint64_t block_kth_largest(const Keys& keys, uint32_t kth, SelectShared& sh) {
   const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
   const int lane = tid & 63, wave = tid >> 6;
   uint64_t prefix = 0;
@@ -73,11 +116,9 @@ __device__ inline uint64_t block_kth_largest(const uint64_t* keys, int64_t m, ui
   for (int shift = 56; shift >= 0; shift -= 8) {
     if (tid < 256) sh.hist[tid] = 0;
     __syncthreads();
-    for (int64_t i = tid; i < m; i += nt) {
-      const uint64_t k = keys[i];
-      if (k != kKeyEmpty && (shift == 56 || (k >> (shift + 8)) == prefix))
-        atomicAdd(&sh.hist[static_cast<uint32_t>(k >> shift) & 0xFFu], 1u);
-    }
+    keys.for_each(tid, nt, [&](uint64_t k) {
+      if (shift == 56 || (k >> (shift + 8)) == prefix) atomicAdd(&sh.hist[static_cast<uint32_t>(k >> shift) & 0xFFu], 1u);
+    });
     __syncthreads();
     uint32_t h = 0, sfx = 0;
     if (tid < 256) {  // waves 0..3, all lanes active

@@ -10,17 +10,17 @@
 
 namespace dewi {
 
+__device__ __forceinline__ int pow2_at_least(int v) {
+  int p = 2;
+  while (p < v) p <<= 1;
+  return p;
+}
+
 __device__ __forceinline__ float blend(const RerankParams& rp, float sim, float dewi, float ent) {
   // reference backends.py:461-465: (1-eta)*s and eta*dewi are rounded separately, then added.
   float adj = __fadd_rn(__fmul_rn(rp.w_sim, sim), __fmul_rn(rp.w_dewi, dewi));
   if (rp.use_ent) adj = __fadd_rn(adj, __fmul_rn(rp.w_ent, ent));
   return adj;
-}
-
-__device__ __forceinline__ int pow2_at_least(int v) {
-  int p = 2;
-  while (p < v) p <<= 1;
-  return p;
 }
 
 // After sh.sel[0..n_sel) holds the candidates sorted by (sim desc, row asc) and dewi/ent of entry t
@@ -74,6 +74,28 @@ __device__ void rerank_and_emit(SelectShared& sh, int n_sel, int k, const Rerank
 // ---------------------------------------------------------------------------------------------
 // Single-device (or per-shard) select: keys from the scan -> final results or candidate records.
 // ---------------------------------------------------------------------------------------------
+// Exact route: 8-bit MSB radix select for the n_candidates-th largest key, compaction of everything at
+// or above it into sh.sel, bitonic sort.  Returns the number of valid keys in sh.sel.
+template <class Keys>
+__device__ int exact_top_candidates(const Keys& keys, int n_candidates, SelectShared& sh) {
+  const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
+  const uint64_t thr = block_kth_largest(keys, static_cast<uint32_t>(n_candidates), sh);
+  if (tid == 0) sh.count = 0;
+  const int p2 = pow2_at_least(n_candidates);
+  for (int t = tid; t < p2; t += nt) sh.sel[t] = kKeyEmpty;
+  __syncthreads();
+  keys.for_each(tid, nt, [&](uint64_t key) {
+    if (key >= thr) {
+      const uint32_t pos = atomicAdd(&sh.count, 1u);
+      if (pos < static_cast<uint32_t>(p2)) sh.sel[pos] = key;
+    }
+  });
+  __syncthreads();
+  const int n_sel = static_cast<int>(sh.count < static_cast<uint32_t>(n_candidates) ? sh.count : n_candidates);
+  bitonic_sort_desc<false>(sh.sel, nullptr, p2);
+  return n_sel;
+}
+
 // Gathers the best n_candidates keys of one query into sh.sel, sorted descending; returns how many
 // are valid.  Two routes:
 //  * sorted lists (the scan's block-merged output: `sorted_lists` lists of n_candidates keys, each
@@ -148,48 +170,42 @@ __device__ int gather_top_candidates(const uint64_t* __restrict__ keys, int64_t 
     }
     // more survivors than LDS holds (degenerate input): exact select below
   }
-  const uint64_t thr = block_kth_largest(keys, keys_per_query, static_cast<uint32_t>(n_candidates), sh);
-  if (tid == 0) sh.count = 0;
-  const int p2 = pow2_at_least(n_candidates);
-  for (int t = tid; t < p2; t += nt) sh.sel[t] = kKeyEmpty;
-  __syncthreads();
-  for (int64_t i = tid; i < keys_per_query; i += nt) {
-    const uint64_t key = keys[i];
-    if (key != kKeyEmpty && key >= thr) {
-      const uint32_t pos = atomicAdd(&sh.count, 1u);
-      if (pos < static_cast<uint32_t>(p2)) sh.sel[pos] = key;
-    }
-  }
-  __syncthreads();
-  const int n_sel = static_cast<int>(sh.count < static_cast<uint32_t>(n_candidates) ? sh.count : n_candidates);
-  bitonic_sort_desc<false>(sh.sel, nullptr, p2);
-  return n_sel;
+  return exact_top_candidates(ArrayKeys{keys, keys_per_query}, n_candidates, sh);
 }
 
 __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(
     const uint64_t* __restrict__ keys_all, int64_t keys_per_query, int sorted_lists, int n_candidates, int k,
     RerankParams rp, const float* __restrict__ dewi32, const float* __restrict__ ent32, int64_t id_offset,
     int64_t* __restrict__ out_ids, float* __restrict__ out_scores, dewi_candidate* __restrict__ out_cand,
-    const uint32_t* __restrict__ counts) {
+    const uint32_t* __restrict__ counts, SegmentLayout seg) {
   __shared__ SelectShared sh;
   const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
   const int q = static_cast<int>(blockIdx.x);
   const uint64_t* keys = keys_all + static_cast<int64_t>(q) * keys_per_query;
-  int64_t n_keys = keys_per_query;
+  int n_sel;
   if (counts != nullptr) {
-    const uint32_t have = counts[q];
-    if (static_cast<int64_t>(have) > keys_per_query) {
-      // the candidate buffer overflowed: this query was NOT answered; the caller re-runs it on the
-      // exact small-batch path (ids = -1 is the documented marker)
+    // Output of the batched matrix-core scan: `seg.n_seg` per-workgroup segments.  A count above the
+    // segment capacity means that buffer overflowed and this query was NOT answered: the caller
+    // re-runs it on the exact small-batch path (ids = -1 is the documented marker).
+    SegmentKeys kv{keys_all + static_cast<int64_t>(q) * seg.cap, counts + q, seg.seg_stride, seg.count_stride, seg.n_seg,
+                   seg.cap, seg.raw != 0};
+    if (tid == 0) sh.total = 0;
+    __syncthreads();
+    for (int s = tid; s < seg.n_seg; s += nt)
+      if (kv.count[s * kv.count_stride] > static_cast<uint32_t>(seg.cap)) sh.total = 1;
+    __syncthreads();
+    if (sh.total) {
       for (int j = tid; j < k; j += nt) {
         out_ids[static_cast<int64_t>(q) * k + j] = -1;
         out_scores[static_cast<int64_t>(q) * k + j] = __builtin_nanf("");
       }
       return;
     }
-    n_keys = have;
+    __syncthreads();
+    n_sel = exact_top_candidates(kv, n_candidates, sh);
+  } else {
+    n_sel = gather_top_candidates(keys, keys_per_query, sorted_lists, n_candidates, sh);
   }
-  const int n_sel = gather_top_candidates(keys, n_keys, sorted_lists, n_candidates, sh);
 
   if (out_cand != nullptr) {
     dewi_candidate* oc = out_cand + static_cast<int64_t>(q) * n_candidates;
@@ -269,7 +285,8 @@ __global__ __launch_bounds__(kSelectThreads) void merge_rerank_kernel(const dewi
 hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, int sorted_lists, int n_queries,
                                 int n_candidates, int k, const RerankParams& rp, const float* d_dewi32,
                                 const float* d_ent32, int64_t id_offset, int64_t* d_out_ids, float* d_out_scores,
-                                dewi_candidate* d_out_cand, const uint32_t* d_counts, hipStream_t stream) {
+                                dewi_candidate* d_out_cand, const uint32_t* d_counts, const SegmentLayout& seg,
+                                hipStream_t stream) {
   int threads = kSelectThreads;
   if (sorted_lists > 0) {
     threads = sorted_lists <= 64 ? 256 : kSelectThreads;
@@ -278,7 +295,7 @@ hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, 
   }
   hipLaunchKernelGGL(select_rerank_kernel, dim3(n_queries), dim3(threads), 0, stream, d_keys, keys_per_query,
                      sorted_lists, n_candidates, k, rp, d_dewi32, d_ent32, id_offset, d_out_ids, d_out_scores,
-                     d_out_cand, d_counts);
+                     d_out_cand, d_counts, seg);
   return hipGetLastError();
 }
 
