@@ -239,6 +239,14 @@ int dewi_normalize_rows_f32(const float* d_src, float* d_dst, int64_t n_rows, in
   return e == hipSuccess ? DEWI_OK : hip_fail(e, "normalize_rows launch");
 }
 
+int dewi_row_cosine_f32(const float* d_a, const float* d_b, float* d_out, int64_t n_rows, int dim, void* stream) {
+  if (n_rows < 0 || dim <= 0) return fail(DEWI_ERR_INVALID_ARG, "bad shape %lld x %d", static_cast<long long>(n_rows), dim);
+  if (n_rows == 0) return DEWI_OK;
+  if (!d_a || !d_b || !d_out) return fail(DEWI_ERR_INVALID_ARG, "null pointer");
+  hipError_t e = dewi::launch_row_cosine(d_a, d_b, d_out, n_rows, dim, 1e-8f, static_cast<hipStream_t>(stream));
+  return e == hipSuccess ? DEWI_OK : hip_fail(e, "row_cosine launch");
+}
+
 int dewi_convert_f32_to_bf16(const float* d_src, uint16_t* d_dst, int64_t n_elems, void* stream) {
   if (n_elems < 0) return fail(DEWI_ERR_INVALID_ARG, "negative element count");
   if (n_elems == 0) return DEWI_OK;

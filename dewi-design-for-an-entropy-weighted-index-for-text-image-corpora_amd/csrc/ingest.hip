@@ -68,6 +68,64 @@ hipError_t launch_normalize_rows(const float* d_src, float* d_dst, int64_t n_row
   return hipGetLastError();
 }
 
+// Row-wise cosine of two N x d matrices: the post-embedding arithmetic of CrossModalDependency
+// (reference src/dewi/signals/cross_modal.py:69, 124-139: F.cosine_similarity of the text and image
+// embeddings of the same document = the I_hat signal).  torch semantics: each vector is divided by
+// max(||x||, eps) with eps = 1e-8.  One wavefront per row; HBM-bound, 2*n*d*4 bytes read.
+template <int VEC>
+__global__ __launch_bounds__(256) void row_cosine_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                         float* __restrict__ out, int64_t n_rows, int dim, float eps) {
+  const int lane = lane_id();
+  const int64_t gwave = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+  for (int64_t row = gwave; row < n_rows; row += n_waves) {
+    const float* a = A + row * dim;
+    const float* b = B + row * dim;
+    float ab = 0.f, aa = 0.f, bb = 0.f;
+    if constexpr (VEC == 4) {
+      const f32x4* av = reinterpret_cast<const f32x4*>(a);
+      const f32x4* bv = reinterpret_cast<const f32x4*>(b);
+      for (int u = lane; u < dim / 4; u += kWave) {
+        const f32x4 x = __builtin_nontemporal_load(av + u), y = __builtin_nontemporal_load(bv + u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          ab = __builtin_fmaf(x[i], y[i], ab);
+          aa = __builtin_fmaf(x[i], x[i], aa);
+          bb = __builtin_fmaf(y[i], y[i], bb);
+        }
+      }
+    } else {
+      for (int j = lane; j < dim; j += kWave) {
+        ab = __builtin_fmaf(a[j], b[j], ab);
+        aa = __builtin_fmaf(a[j], a[j], aa);
+        bb = __builtin_fmaf(b[j], b[j], bb);
+      }
+    }
+    ab = wave_sum_f32(ab);
+    aa = wave_sum_f32(aa);
+    bb = wave_sum_f32(bb);
+    if (lane == 0) {
+      const float na = __builtin_fmaxf(__fsqrt_rn(aa), eps), nb = __builtin_fmaxf(__fsqrt_rn(bb), eps);
+      out[row] = __fdiv_rn(ab, __fmul_rn(na, nb));
+    }
+  }
+}
+
+hipError_t launch_row_cosine(const float* d_a, const float* d_b, float* d_out, int64_t n_rows, int dim, float eps,
+                             hipStream_t stream) {
+  if (n_rows <= 0) return hipSuccess;
+  int64_t blocks = (n_rows + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  const bool vec = dim % 4 == 0 && (reinterpret_cast<uintptr_t>(d_a) % 16 == 0) && (reinterpret_cast<uintptr_t>(d_b) % 16 == 0);
+  if (vec)
+    hipLaunchKernelGGL(row_cosine_kernel<4>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, d_a, d_b, d_out,
+                       n_rows, dim, eps);
+  else
+    hipLaunchKernelGGL(row_cosine_kernel<1>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, d_a, d_b, d_out,
+                       n_rows, dim, eps);
+  return hipGetLastError();
+}
+
 // fp32 -> bf16, round to nearest even; NaN stays NaN (quiet bit forced).
 __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
   const uint32_t u = __float_as_uint(f);

@@ -111,6 +111,8 @@ hipError_t launch_merge_rerank(const dewi_candidate* d_lists, int n_lists, int n
 
 // ---- ingest.hip ---------------------------------------------------------------------------
 hipError_t launch_normalize_rows(const float* d_src, float* d_dst, int64_t n_rows, int dim, hipStream_t stream);
+hipError_t launch_row_cosine(const float* d_a, const float* d_b, float* d_out, int64_t n_rows, int dim, float eps,
+                             hipStream_t stream);
 hipError_t launch_f32_to_bf16(const float* d_src, uint16_t* d_dst, int64_t n, hipStream_t stream);
 hipError_t launch_payload_soa(const double* dewi, const double* ht, const double* hi, float* dewi32, float* ent32,
                               int64_t n, hipStream_t stream);

@@ -34,7 +34,7 @@ ABI_VERSION = 1
 #: every symbol include/dewi_hip.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = (
     "dewi_abi_version", "dewi_last_error", "dewi_device_info", "dewi_normalize_rows_f32",
-    "dewi_convert_f32_to_bf16", "dewi_payload_soa_f64", "dewi_knn_workspace_bytes", "dewi_knn_rerank_f32",
+    "dewi_row_cosine_f32", "dewi_convert_f32_to_bf16", "dewi_payload_soa_f64", "dewi_knn_workspace_bytes", "dewi_knn_rerank_f32",
     "dewi_knn_rerank_bf16", "dewi_knn_scan", "dewi_knn_finish", "dewi_knn_candidates", "dewi_merge_rerank", "dewi_robust_fit_workspace_bytes",
     "dewi_robust_fit_f32", "dewi_score_f64", "dewi_timing_enable", "dewi_timing_read", "dewi_tuning_set",
 )
@@ -63,6 +63,8 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.dewi_device_info.argtypes = [c.POINTER(i32), c.POINTER(i32), c.POINTER(sz)]
     lib.dewi_normalize_rows_f32.restype = i32
     lib.dewi_normalize_rows_f32.argtypes = [vp, vp, i64, i32, vp]
+    lib.dewi_row_cosine_f32.restype = i32
+    lib.dewi_row_cosine_f32.argtypes = [vp, vp, vp, i64, i32, vp]
     lib.dewi_convert_f32_to_bf16.restype = i32
     lib.dewi_convert_f32_to_bf16.argtypes = [vp, vp, i64, vp]
     lib.dewi_payload_soa_f64.restype = i32

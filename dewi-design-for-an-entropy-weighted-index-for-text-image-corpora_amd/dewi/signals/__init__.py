@@ -1,0 +1,79 @@
+"""Embedding-space signals for DEWI on the GPU.
+
+The reference's ``dewi.signals`` estimators run HuggingFace models (GPT-2, ViT-MAE, CLIP) and are
+outside the hot path this package rebuilds; the five estimator names are exported as ``None``
+placeholders, exactly what the reference's own ``signals/__init__.py:11-34`` does when an optional
+dependency is missing.  What IS provided is the arithmetic those estimators perform AFTER the
+embedding models, on embeddings the caller already has:
+
+* ``cross_modal_similarity`` — the ``I_hat`` signal: row-wise ``F.cosine_similarity`` of the text and
+  image embeddings of the same document (reference ``signals/cross_modal.py:69, 124-139``).
+* ``redundancy_top1`` — a per-document reduction of the text x image similarity matrix the reference's
+  ``RedundancyEstimator`` returns (``signals/redundancy.py:28-39``).  The reference never defines
+  such a reduction (``pipelines.py:148-149`` calls methods that do not exist), so this one —
+  similarity of a document's text to the closest image of any OTHER document — is this package's
+  own definition: parity unpinned.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from .. import _native as nat
+
+TextEntropyEstimator = None
+ImageEntropyEstimator = None
+CrossModalDependency = None
+RedundancyEstimator = None
+NoiseEstimator = None
+
+
+def cross_modal_similarity(text_emb, image_emb) -> np.ndarray:
+    """``I_hat[i] = cos(text_emb[i], image_emb[i])`` for [N, d] fp32 arrays (host or CUDA tensors)."""
+    import torch
+    lib = nat.load_library()
+    a = text_emb if isinstance(text_emb, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(text_emb, dtype=np.float32))
+    b = image_emb if isinstance(image_emb, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(image_emb, dtype=np.float32))
+    if a.shape != b.shape or a.dim() != 2:
+        raise ValueError(f"expected two [N, d] arrays of the same shape, got {tuple(a.shape)} and {tuple(b.shape)}")
+    a = a.to(device="cuda", dtype=torch.float32).contiguous()
+    b = b.to(device="cuda", dtype=torch.float32).contiguous()
+    out = torch.empty(a.shape[0], dtype=torch.float32, device=a.device)
+    nat.check(lib.dewi_row_cosine_f32(nat.ptr(a), nat.ptr(b), nat.ptr(out), a.shape[0], a.shape[1], nat.stream_ptr()))
+    return out.cpu().numpy()
+
+
+def redundancy_top1(text_emb: np.ndarray, image_emb: np.ndarray, batch: int = 1024, bf16: Optional[bool] = None
+                    ) -> np.ndarray:
+    """Highest cosine similarity between document i's text and the image of any other document.
+
+    Self-join through the kNN kernels: the normalised image embeddings are the corpus, the text
+    embeddings the queries, k = 2 (the best match that is not the document itself).  ``bf16``
+    (default: for 64K+ rows) stores the corpus in bf16 and uses the batched matrix-core path.
+    """
+    from .._engine import DeviceCorpus
+    t = np.ascontiguousarray(text_emb, dtype=np.float32)
+    im = np.ascontiguousarray(image_emb, dtype=np.float32)
+    if t.shape != im.shape or t.ndim != 2:
+        raise ValueError(f"expected two [N, d] arrays of the same shape, got {t.shape} and {im.shape}")
+    n = t.shape[0]
+    if n < 2:
+        return np.zeros(n, np.float32)
+    zeros = np.zeros(n)
+    corpus = DeviceCorpus.from_host(im, zeros, zeros, zeros, "cosine")
+    if bf16 is None:
+        bf16 = n >= 65536
+    if bf16:
+        corpus = corpus.to_bf16()
+    out = np.empty(n, np.float32)
+    for s in range(0, n, batch):
+        e = min(n, s + batch)
+        ids, sims = corpus.search(t[s:e], k=2, eta=0.0, entropy_pref=0.0)     # eta = 0: adjusted score == similarity
+        own = ids[:, 0] == np.arange(s, e)
+        out[s:e] = np.where(own, sims[:, 1], sims[:, 0])
+    return out
+
+
+__all__ = ["TextEntropyEstimator", "ImageEntropyEstimator", "CrossModalDependency", "RedundancyEstimator",
+           "NoiseEstimator", "cross_modal_similarity", "redundancy_top1"]

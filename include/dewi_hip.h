@@ -77,6 +77,11 @@ int dewi_device_info(int* out_compute_units, int* out_wavefront, size_t* out_tot
  * ------------------------------------------------------------------------------------------ */
 int dewi_normalize_rows_f32(const float* d_src, float* d_dst, int64_t n_rows, int dim, void* stream);
 
+/* F3  I_hat signal — replaces the post-embedding arithmetic of CrossModalDependency
+ * (signals/cross_modal.py:69, 124-139): out[i] = F.cosine_similarity(A[i], B[i]) with torch's
+ * semantics (each vector divided by max(||x||, 1e-8)).  A, B [n_rows][dim] fp32 row-major. */
+int dewi_row_cosine_f32(const float* d_a, const float* d_b, float* d_out, int64_t n_rows, int dim, void* stream);
+
 /* fp32 -> bf16 (round to nearest even, NaN preserved) for the bf16 corpus of config C3. */
 int dewi_convert_f32_to_bf16(const float* d_src, uint16_t* d_dst, int64_t n_elems, void* stream);
 
