@@ -94,6 +94,8 @@ struct KnnLayout {
   dewi::ScanPlan plan;
   size_t keys_off, keys_bytes;
   size_t qn_off, qn_bytes;
+  size_t big_off, big_bytes;  // 2 x [n_queries][p2] u64 scratch when n_candidates > kMaxSortCandidates
+  int p2;
   size_t total;
 };
 
@@ -104,7 +106,16 @@ KnnLayout layout_knn(int64_t n_rows, int dim, int elem_bytes, int n_queries, int
   L.keys_bytes = align_up(static_cast<size_t>(n_queries) * static_cast<size_t>(L.plan.keys_per_query) * 8, 256);
   L.qn_off = L.keys_off + L.keys_bytes;
   L.qn_bytes = align_up(static_cast<size_t>(n_queries) * dim * 4, 256);
-  L.total = L.qn_off + L.qn_bytes;
+  L.big_off = L.qn_off + L.qn_bytes;
+  L.p2 = 0;
+  L.big_bytes = 0;
+  if (n_candidates > dewi::kMaxSortCandidates) {
+    int p2 = 2;
+    while (p2 < n_candidates) p2 <<= 1;
+    L.p2 = p2;
+    L.big_bytes = align_up(static_cast<size_t>(2) * n_queries * p2 * 8, 256);
+  }
+  L.total = L.big_off + L.big_bytes;
   return L;
 }
 
@@ -167,9 +178,7 @@ int knn_rerank_impl(const void* d_E, int elem_type, int64_t n_rows, int dim, con
                 static_cast<long long>(n_rows));
   if (!d_dewi32 || !d_ent32 || !d_out_ids || !d_out_scores) return fail(DEWI_ERR_INVALID_ARG, "null payload or output pointer");
   const int64_t c64 = (2ll * k < n_rows) ? 2ll * k : n_rows;
-  if (c64 > dewi::kMaxSortCandidates)
-    return fail(DEWI_ERR_UNSUPPORTED, "candidate count %lld (= min(2k, n_rows)) exceeds %d", static_cast<long long>(c64),
-                dewi::kMaxSortCandidates);
+  if (c64 > (1ll << 30)) return fail(DEWI_ERR_UNSUPPORTED, "candidate count %lld exceeds 2^30", static_cast<long long>(c64));
   const int c = static_cast<int>(c64);
   DeviceInfo dev;
   rc = ensure_device(dev);
@@ -207,6 +216,15 @@ int knn_rerank_impl(const void* d_E, int elem_type, int64_t n_rows, int dim, con
   rc = run_scan(L, d_E, elem_type, n_rows, dim, d_Q, n_queries, c, space, ws, stream);
   if (rc) return rc;
   const dewi::RerankParams rp = make_rerank(eta, pref);
+  if (c > dewi::kMaxSortCandidates) {  // k > 1024: candidate arrays live in global memory
+    uint64_t* g1 = reinterpret_cast<uint64_t*>(ws + L.big_off);
+    hipError_t e2 = dewi::launch_select_rerank_large(reinterpret_cast<const uint64_t*>(ws + L.keys_off),
+                                                     L.plan.keys_per_query, n_queries, c, L.p2, k, rp, d_dewi32, d_ent32, g1,
+                                                     g1 + static_cast<size_t>(n_queries) * L.p2, d_out_ids, d_out_scores,
+                                                     stream);
+    if (e2 != hipSuccess) return hip_fail(e2, "select_rerank_large launch");
+    return DEWI_OK;
+  }
   hipError_t e = dewi::launch_select_rerank(reinterpret_cast<const uint64_t*>(ws + L.keys_off), L.plan.keys_per_query,
                                             L.plan.slots == 1 ? L.plan.n_lists : 0, n_queries, c, k, rp, d_dewi32, d_ent32, 0, d_out_ids, d_out_scores, nullptr,
                                             nullptr, dewi::SegmentLayout{}, stream);

@@ -282,6 +282,82 @@ __global__ __launch_bounds__(kSelectThreads) void merge_rerank_kernel(const dewi
                   out_scores + static_cast<int64_t>(q) * k);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Large candidate counts (c > kMaxSortCandidates, i.e. k > 1024): same steps with the candidate
+// arrays in global memory instead of LDS.  One workgroup per query; g1/g2 are [n_queries][p2]
+// scratch arrays (p2 = power of two >= c).  Not a fast path — it exists so that every k the
+// reference accepts (up to k == N) is answered.
+// ---------------------------------------------------------------------------------------------
+__device__ void bitonic_sort_desc_global(uint64_t* key, int p2) {
+  const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
+  for (int size = 2; size <= p2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();  // all waves of the workgroup share one CU and its L1: block-level visibility
+      for (int t = tid; t < (p2 >> 1); t += nt) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool first_half = (lo & size) == 0;
+        const uint64_t a = key[lo], b = key[hi];
+        if (first_half ? (a < b) : (a > b)) {
+          key[lo] = b;
+          key[hi] = a;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kSelectThreads) void select_rerank_large_kernel(
+    const uint64_t* __restrict__ keys_all, int64_t keys_per_query, int n_candidates, int p2, int k, RerankParams rp,
+    const float* __restrict__ dewi32, const float* __restrict__ ent32, uint64_t* __restrict__ g1_all,
+    uint64_t* __restrict__ g2_all, int64_t* __restrict__ out_ids, float* __restrict__ out_scores) {
+  __shared__ SelectShared sh;
+  const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
+  const int q = static_cast<int>(blockIdx.x);
+  const ArrayKeys keys{keys_all + static_cast<int64_t>(q) * keys_per_query, keys_per_query};
+  uint64_t* g1 = g1_all + static_cast<int64_t>(q) * p2;
+  uint64_t* g2 = g2_all + static_cast<int64_t>(q) * p2;
+  const uint64_t thr = block_kth_largest(keys, static_cast<uint32_t>(n_candidates), sh);
+  if (tid == 0) sh.count = 0;
+  for (int t = tid; t < p2; t += nt) g1[t] = kKeyEmpty;
+  __syncthreads();
+  keys.for_each(tid, nt, [&](uint64_t key) {
+    if (key >= thr) {
+      const uint32_t pos = atomicAdd(&sh.count, 1u);
+      if (pos < static_cast<uint32_t>(p2)) g1[pos] = key;
+    }
+  });
+  __syncthreads();
+  const int n_sel = static_cast<int>(sh.count < static_cast<uint32_t>(n_candidates) ? sh.count : n_candidates);
+  bitonic_sort_desc_global(g1, p2);                       // (sim desc, row asc)
+  for (int t = tid; t < p2; t += nt) {
+    uint64_t k2 = kKeyEmpty;
+    if (t < n_sel) {
+      const uint32_t row = key_row(g1[t]);
+      const float adj = blend(rp, key_score(g1[t]), dewi32[row], ent32[row]);
+      k2 = (static_cast<uint64_t>(ord_f32(adj)) << 32) | static_cast<uint64_t>(0xFFFFFFFFu - static_cast<uint32_t>(t));
+    }
+    g2[t] = k2;
+  }
+  bitonic_sort_desc_global(g2, p2);
+  for (int j = tid; j < k && j < n_sel; j += nt) {
+    const uint64_t k2 = g2[j];
+    const uint32_t t = 0xFFFFFFFFu - static_cast<uint32_t>(k2);
+    out_ids[static_cast<int64_t>(q) * k + j] = key_row(g1[t]);
+    out_scores[static_cast<int64_t>(q) * k + j] = unord_f32(static_cast<uint32_t>(k2 >> 32));
+  }
+}
+
+hipError_t launch_select_rerank_large(const uint64_t* d_keys, int64_t keys_per_query, int n_queries, int n_candidates,
+                                      int p2, int k, const RerankParams& rp, const float* d_dewi32,
+                                      const float* d_ent32, uint64_t* d_g1, uint64_t* d_g2, int64_t* d_out_ids,
+                                      float* d_out_scores, hipStream_t stream) {
+  hipLaunchKernelGGL(select_rerank_large_kernel, dim3(n_queries), dim3(kSelectThreads), 0, stream, d_keys,
+                     keys_per_query, n_candidates, p2, k, rp, d_dewi32, d_ent32, d_g1, d_g2, d_out_ids, d_out_scores);
+  return hipGetLastError();
+}
+
 hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, int sorted_lists, int n_queries,
                                 int n_candidates, int k, const RerankParams& rp, const float* d_dewi32,
                                 const float* d_ent32, int64_t id_offset, int64_t* d_out_ids, float* d_out_scores,
