@@ -61,7 +61,8 @@ dewi::Tuning g_tuning{0, 0, -1, 1};
 
 // ---- timing ring -----------------------------------------------------------------------------
 struct Timing {
-  bool enabled = false;
+  int every = 0;          // 0 = off; n = bracket every n-th scan with events
+  unsigned long calls = 0;
   std::vector<hipEvent_t> start, stop;
   size_t used = 0;
 } g_timing;
@@ -72,7 +73,8 @@ struct ScanTimer {
   hipEvent_t stop = nullptr;
   explicit ScanTimer(hipStream_t s) : stream(s) {
     std::lock_guard<std::mutex> lk(g_timing_mu);
-    if (!g_timing.enabled) return;
+    if (g_timing.every <= 0) return;
+    if ((g_timing.calls++ % static_cast<unsigned long>(g_timing.every)) != 0) return;
     if (g_timing.used == g_timing.start.size()) {
       hipEvent_t a, b;
       if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
@@ -450,9 +452,10 @@ int dewi_score_f64(const void* d_S, int signals_are_f64, int64_t n, int64_t ld, 
   return e == hipSuccess ? DEWI_OK : hip_fail(e, "score launch");
 }
 
-int dewi_timing_enable(int enable) {
+int dewi_timing_enable(int every) {
   std::lock_guard<std::mutex> lk(g_timing_mu);
-  g_timing.enabled = enable != 0;
+  g_timing.every = every > 0 ? every : 0;
+  g_timing.calls = 0;
   g_timing.used = 0;
   return DEWI_OK;
 }

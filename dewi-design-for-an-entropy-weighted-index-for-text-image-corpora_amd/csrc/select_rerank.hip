@@ -30,12 +30,14 @@ __device__ void rerank_and_emit(SelectShared& sh, int n_sel, int k, const Rerank
                                 int64_t* __restrict__ out_ids, float* __restrict__ out_scores) {
   const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
   const int p2 = pow2_at_least(n_sel);
+  int64_t my_id = -1;  // id of candidate t == tid, kept in a register for the one-candidate-per-thread case
   for (int t = tid; t < p2; t += nt) {
     uint64_t k2 = kKeyEmpty;
     if (t < n_sel) {
       float dewi, ent;
       int64_t id;
       fetch(t, dewi, ent, id);
+      if (t == tid) my_id = id;
       const float adj = blend(rp, key_score(sh.sel[t]), dewi, ent);
       // ties on the adjusted score: the candidate that ranked higher on similarity first
       k2 = (static_cast<uint64_t>(ord_f32(adj)) << 32) | static_cast<uint64_t>(0xFFFFFFFFu - static_cast<uint32_t>(t));
@@ -50,9 +52,11 @@ __device__ void rerank_and_emit(SelectShared& sh, int n_sel, int k, const Rerank
       int rank = 0;
       for (int j = 0; j < n_sel; ++j) rank += sh.sel2[j] > mine ? 1 : 0;  // adjusted keys are unique (low word = t)
       if (rank < k) {
-        float dewi, ent;
-        int64_t id;
-        fetch(t, dewi, ent, id);
+        int64_t id = my_id;
+        if (t != tid) {  // more candidates than threads: fetch again
+          float dewi, ent;
+          fetch(t, dewi, ent, id);
+        }
         out_ids[rank] = id;
         out_scores[rank] = unord_f32(static_cast<uint32_t>(mine >> 32));
       }
@@ -109,7 +113,14 @@ __device__ int gather_top_candidates(const uint64_t* __restrict__ keys, int64_t 
                                      int n_candidates, SelectShared& sh) {
   const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
   if (sorted_lists > 0 && sorted_lists <= kMaxSortCandidates) {
-    for (int t = tid; t < sorted_lists; t += nt) sh.sel2[t] = keys[static_cast<int64_t>(t) * n_candidates];
+    // list maxima (entry 0); entry 1 is loaded in the same round trip because the owner of a
+    // contributing list almost always needs it a moment later
+    uint64_t second = kKeyEmpty;
+    for (int t = tid; t < sorted_lists; t += nt) {
+      const uint64_t* lst = keys + static_cast<int64_t>(t) * n_candidates;
+      sh.sel2[t] = lst[0];
+      if (t == tid && n_candidates > 1) second = lst[1];
+    }
     if (tid == 0) {
       sh.count = 0;
       sh.total = 0;       // "a list maximum ranked c-th" flag
@@ -150,7 +161,7 @@ __device__ int gather_top_candidates(const uint64_t* __restrict__ keys, int64_t 
       if (!all_lists && sh.val[t] >= static_cast<uint32_t>(n_candidates)) continue;
       const uint64_t* lst = keys + static_cast<int64_t>(t) * n_candidates;
       for (int j = 0; j < n_candidates; ++j) {
-        const uint64_t key = lst[j];
+        const uint64_t key = (j == 1 && t == tid) ? second : lst[j];
         if (key == kKeyEmpty || key < bound) break;
         const uint32_t pos = atomicAdd(&sh.count, 1u);
         if (pos < static_cast<uint32_t>(kMaxSortCandidates)) sh.sel2[pos] = key;

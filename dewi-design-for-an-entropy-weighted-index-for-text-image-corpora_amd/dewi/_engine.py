@@ -296,8 +296,9 @@ def records_to_numpy(recs) -> np.ndarray:
     return np.ascontiguousarray(a).view(dt).reshape(a.shape[:-1])
 
 
-def timing(enable: bool) -> None:
-    nat.check(nat.load_library().dewi_timing_enable(1 if enable else 0))
+def timing(every) -> None:
+    """Bracket every ``every``-th scan with hipEvents (True == 1: every scan; False / 0: off)."""
+    nat.check(nat.load_library().dewi_timing_enable(int(every)))
 
 
 def timing_read() -> Tuple[float, int]:

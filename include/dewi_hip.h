@@ -183,11 +183,13 @@ int dewi_score_f64(const void* d_S, int signals_are_f64, int64_t n, int64_t ld, 
                    float* d_out32, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Measurement hooks (bench.py): when enabled, every dewi_knn_* call brackets its corpus-scan
- * kernel with hipEvents on `stream`; dewi_timing_read synchronises those events and returns the
- * mean scan-kernel duration in milliseconds and the number of launches averaged, then resets.
+ * Measurement hooks (bench.py): dewi_timing_enable(n) makes every n-th dewi_knn_* call bracket its
+ * corpus-scan kernel with hipEvents on `stream` (n = 1: every call; 0: off — the two event records
+ * cost ~5 us of stream time, so throughput runs sample); dewi_timing_read synchronises those
+ * events and returns the mean scan-kernel duration in milliseconds and the number of launches
+ * averaged, then resets.
  * ------------------------------------------------------------------------------------------ */
-int dewi_timing_enable(int enable);
+int dewi_timing_enable(int every);
 int dewi_timing_read(double* out_mean_scan_ms, int* out_launches);
 
 /* Launch-shape overrides for tuning sweeps (0 / -1 = planner default).  batched_mfma = 0 disables the

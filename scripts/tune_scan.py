@@ -26,6 +26,7 @@ ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--bf16", action="store_true")
+ap.add_argument("--no-timing", action="store_true", help="do not bracket scans with hipEvents (step time only)")
 ap.add_argument("cfgs", nargs="+")
 a = ap.parse_args()
 
@@ -46,13 +47,13 @@ for rnd in range(a.rounds + 1):
         for j in range(10):
             corpus.search_device(Q[j], a.k, 0.3, 0.0)
         torch.cuda.synchronize()
-        eng.timing(True)
+        eng.timing(not a.no_timing)
         t0 = time.perf_counter()
         for j in range(a.steps):
             corpus.search_device(Q[j % 64], a.k, 0.3, 0.0)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / a.steps * 1e3
-        ms, n = eng.timing_read()
+        ms, n = eng.timing_read() if not a.no_timing else (0.0, 0)
         eng.timing(False)
         if rnd:  # round 0 is warm-up
             res[c]["scan"].append(ms)
