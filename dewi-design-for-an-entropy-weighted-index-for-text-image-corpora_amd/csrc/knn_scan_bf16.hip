@@ -30,6 +30,22 @@ __device__ __forceinline__ float round_to_bf16(float f) {
   return __uint_as_float((u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u);
 }
 
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// Cosine: 8 bf16 x bf16 products accumulated in fp32 with v_dot2c_f32_bf16 — the corpus dwords and the
+// packed query dwords are both (element 2i | element 2i+1 << 16), so no unpacking at all: 4 VALU
+// instructions per 16 bytes instead of 16 (shift, mask, 2 FMAs per dword).
+__device__ __forceinline__ float dot8_packed(u32x4 e, const uint32_t (&q)[4], float acc) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    // copy the lane to a scalar first: __builtin_bit_cast applied directly to a vector subscript
+    // (e[i]) made hipcc 7.2 use element 0 for every i
+    const uint32_t ew = e[i], qw = q[i];
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, ew), __builtin_bit_cast(bf16x2, qw), acc, false);
+  }
+  return acc;
+}
+
 template <int SPACE>
 __device__ __forceinline__ float dot8(u32x4 e, const float (&q)[8], float acc) {
 #pragma unroll
@@ -98,6 +114,24 @@ __global__ __launch_bounds__(kScanThreads) void scan_rows_bf16(const uint16_t* _
     }
   }
 
+  // cosine: keep the query as packed bf16 pairs (half the registers, feeds v_dot2c directly)
+  uint32_t qp[NQ][H][4];
+  if constexpr (SPACE == DEWI_SPACE_COSINE) {
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+#pragma unroll
+      for (int j = 0; j < H; ++j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          qp[qi][j][i] = (__float_as_uint(qf[qi][j][2 * i]) >> 16) | (__float_as_uint(qf[qi][j][2 * i + 1]) & 0xFFFF0000u);
+      }
+    }
+  }
+  auto dot = [&](u32x4 e, int qi, int j, float acc) {
+    if constexpr (SPACE == DEWI_SPACE_COSINE) return dot8_packed(e, qp[qi][j], acc);
+    else return dot8<SPACE>(e, qf[qi][j], acc);
+  };
+
   WaveList<DENSE ? 1 : S> lst[DENSE ? 1 : NQ];
   if constexpr (!DENSE) {
 #pragma unroll
@@ -120,11 +154,11 @@ __global__ __launch_bounds__(kScanThreads) void scan_rows_bf16(const uint16_t* _
 #pragma unroll
       for (int j = 0; j < H; ++j) {
         if (2 * j + 1 < H) {            // whole load in the first row
-          a0 = dot8<SPACE>(v[j], qf[qi][j], a0);
+          a0 = dot(v[j], qi, j, a0);
         } else if (2 * j >= H) {        // whole load in the second row
-          a1 = dot8<SPACE>(v[j], qf[qi][j], a1);
+          a1 = dot(v[j], qi, j, a1);
         } else {                        // odd H: lanes 0-31 first row, lanes 32-63 second row
-          const float t = dot8<SPACE>(v[j], qf[qi][j], 0.f);
+          const float t = dot(v[j], qi, j, 0.f);
           a0 += second[j] ? 0.f : t;
           a1 += second[j] ? t : 0.f;
         }

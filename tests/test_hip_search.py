@@ -252,3 +252,30 @@ def test_large_k_global_memory_path(n, k):
         assert np.allclose(np.sort(sc[j]), np.sort(ref_sc), rtol=0, atol=1e-5)
         agree = np.mean(ids[j] == ref_ids)
         assert agree > 0.97, agree
+
+
+def test_pipelined_searcher_equals_serial_search():
+    """dewi_knn_scan / dewi_knn_finish on two streams (PipelinedSearcher) == the one-call search,
+    for final results and for shard candidate records."""
+    import torch
+    eng = _engine()
+    n, d, k = 30_000, 768, 10
+    raw = orc.synth_corpus(n, d, seed=11)
+    cols = orc.synth_payload_columns(n, seed=11)
+    c = _corpus(raw, cols)
+    Q = torch.from_numpy(orc.synth_queries(12, d, seed=12)).cuda()
+    want_ids, want_sc = c.search_device(Q, k, 0.3, 0.1)
+    pipe = eng.PipelinedSearcher(c, k, 0.3, 0.1, n_queries=1)
+    ids = torch.empty((12, 1, k), dtype=torch.int64, device="cuda")
+    sc = torch.empty((12, 1, k), dtype=torch.float32, device="cuda")
+    for j in range(12):
+        pipe.submit(Q[j:j + 1], ids[j], sc[j])
+    pipe.drain()
+    assert torch.equal(ids[:, 0], want_ids) and torch.equal(sc[:, 0], want_sc)
+    recs = torch.empty((12, 1, 2 * k, 4), dtype=torch.int32, device="cuda")
+    pipe2 = eng.PipelinedSearcher(c, k, 0.3, 0.1, n_queries=1, n_candidates=2 * k)
+    for j in range(12):
+        pipe2.submit(Q[j:j + 1], out_records=recs[j])
+    pipe2.drain()
+    want = c.candidates_device(Q, 2 * k)
+    assert torch.equal(recs[:, 0], want)
