@@ -202,7 +202,8 @@ int knn_rerank_impl(const void* d_E, int elem_type, int64_t n_rows, int dim, con
     for (int g = 0; g < M.groups; ++g) {
       const int q0 = g * 256;
       const int nq = n_queries - q0 < 256 ? n_queries - q0 : 256;
-      const dewi::SegmentLayout seg{M.n_seg, M.seg_cap, 1, static_cast<int64_t>(256) * M.seg_cap, 256};
+      // expected survivors per query: 32 c; stage up to 8192 of them (64 KiB) in LDS
+      const dewi::SegmentLayout seg{M.n_seg, M.seg_cap, 1, static_cast<int64_t>(256) * M.seg_cap, 256, 8192};
       const uint64_t* keys = reinterpret_cast<const uint64_t*>(ws + M.cand_off) +
                              static_cast<int64_t>(g) * M.n_seg * 256 * M.seg_cap;
       const uint32_t* counts = reinterpret_cast<const uint32_t*>(ws + M.cnt_off) + static_cast<int64_t>(g) * M.n_seg * 256;

@@ -14,9 +14,10 @@
 //    fragments (dim/16 x 4 VGPRs = 192 of the 256 available at dim 768) are loaded once.  No query
 //    traffic, no LDS for Q.
 //  * DOCUMENT TILES GO THROUGH LDS BY DMA.  A tile (32 rows x dim bf16 = 48 KiB) is copied
-//    global->LDS with global_load_lds_dwordx4 (1 KiB per wave-instruction, no VGPR staging),
-//    double-buffered: tile i+1 is in flight while tile i is multiplied (counted vmcnt, raw
-//    s_barrier).  All 8 waves read the same tile (A operand) with ds_read_b128.
+//    global->LDS with buffer_load_dwordx4 ... lds (1 KiB per wave-instruction, no VGPR staging)
+//    into a ring of three slots: tiles i+1 and i+2 are in flight while tile i is multiplied
+//    (counted vmcnt, one raw s_barrier per tile).  With two slots a tile had one matrix block
+//    (~3 K cycles) to arrive, about one loaded HBM latency: 96 KiB in flight per CU fixes that.  All 8 waves read the same tile (A operand) with ds_read_b128.
 //  * BANK CONFLICTS: rows are 1536 B apart (= 0 mod 256 B), so an A-fragment read (16 lanes = 16
 //    rows, same 16-byte column unit) would be 16-way conflicted.  The LDS image is linear (DMA
 //    writes base + lane*16) and the SOURCE address is permuted instead: unit c of row r is stored
@@ -50,6 +51,7 @@ constexpr int kMfmaThreads = 64 * (8 / kQB);
 constexpr int kTileRows = 32;
 constexpr int kQueriesPerPass = 256;  // 8 waves x 32 (or 4 x 64)
 constexpr int kSampleStride = 32;     // every 32nd tile is a sample tile
+constexpr int kTileBufs = 3;          // LDS ring: the tile being multiplied + two tiles of DMA in flight
 #ifndef DEWI_MFMA_ABLATE
 #define DEWI_MFMA_ABLATE 0   // timing experiments only: 1 no epilogue, 2 no DMA after the first tile, 3 no MFMA
 #endif
@@ -92,7 +94,8 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
     const uint16_t* __restrict__ E, int64_t n_rows, const uint16_t* __restrict__ Qb, int64_t n_tiles,
     int64_t tile_stride, const float* __restrict__ thr, uint64_t* __restrict__ out, int64_t out_stride,
     uint32_t* __restrict__ cnt) {
-  // DENSE: out[q * out_stride + sample position] for every document of the (strided) tiles.
+  // DENSE: `out` is a float array: out[q * out_stride + sample position] = score of every document of the
+  //        (strided) tiles.
   // filter: raw records out[((2*blockIdx.x + h) * 256 + q) * out_stride + slot], cnt[(2*blockIdx.x + h) * 256 + q].
 #if defined(__HIP_DEVICE_COMPILE__)  // the body holds gfx950 inline asm: the host pass only needs the launch stub
   constexpr int DIM = KS * 16;
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
   constexpr int NW = kMfmaThreads / kWave;         // waves per workgroup
   constexpr int PPW = PIECES / NW;                 // pieces per wave
   static_assert(KS % 8 == 0 && KS <= 48, "dim must be a multiple of 128, at most 768");
-  extern __shared__ __attribute__((aligned(16))) char lds[];  // 2 x TILE_BYTES
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // kTileBufs x TILE_BYTES
 
   const int lane = lane_id();
   const int wave = static_cast<int>(threadIdx.x) >> 6;
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
   }
   // ---- per-lane A-fragment read offsets inside a tile buffer
   const int z = (r & 15) ^ h;
-  uint32_t a_addr[8];  // LDS byte addresses for buffer 0; flipped to the other buffer in place every tile
+  uint32_t a_addr[8];  // LDS byte addresses for ring slot 0; advanced to the next slot in place every tile
 #pragma unroll
   for (int j = 0; j < 8; ++j)
     a_addr[j] = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((LdsPtr)(lds))) +
@@ -181,23 +184,38 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
 
   const int64_t first = static_cast<int64_t>(blockIdx.x);
   const int64_t step = static_cast<int64_t>(gridDim.x);
+  // Prologue: the first two tiles of this workgroup go out at once (ring slots 0 and 1).
   if (first < n_tiles) {
     const __amdgpu_buffer_rsrc_t rs = tile_rsrc(first * tile_stride);
 #pragma unroll
     for (int i = 0; i < PPW; ++i) issue_piece(rs, 0, i);
   }
+  if (first + step < n_tiles && DEWI_MFMA_ABLATE != 2) {
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc((first + step) * tile_stride);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) issue_piece(rs, 1, i);
+  }
   int buf = 0;
   for (int64_t i = first; i < n_tiles; i += step) {
     const int64_t tile = i * tile_stride;
-    const bool has_next = (i + step < n_tiles) && DEWI_MFMA_ABLATE != 2;
-    // This tile's pieces were issued during the previous tile's matrix block (or in the prologue);
-    // nothing younger is in flight except that iteration's few survivor stores.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // tile i+2 is fetched while tile i is multiplied: a tile has two whole iterations to land
+    const bool has_next2 = (i + 2 * step < n_tiles) && DEWI_MFMA_ABLATE != 2;
+    const bool has_next1 = (i + step < n_tiles) && DEWI_MFMA_ABLATE != 2;
+    // Outstanding, oldest first: this tile's pieces, the next tile's pieces (issued during the previous
+    // matrix block), then the previous epilogue's few survivor stores.  Leaving the PPW youngest
+    // operations in flight therefore guarantees this tile has landed (it over-waits by one piece per
+    // survivor store, which is harmless).
+    if (has_next1) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();   // (a) every wave's pieces of this tile have landed
-                                    // (b) every wave has finished reading the OTHER buffer, which
-                                    //     the DMA below starts refilling
+                                    // (b) every wave has finished reading the slot of tile i-1, which
+                                    //     the DMA of tile i+2 (issued below) refills
     asm volatile("" ::: "memory");
-    const __amdgpu_buffer_rsrc_t next_rsrc = tile_rsrc(has_next ? (i + step) * tile_stride : tile);
+    const int buf2 = buf + 2 >= kTileBufs ? buf + 2 - kTileBufs : buf + 2;
+    const __amdgpu_buffer_rsrc_t next_rsrc = tile_rsrc(has_next2 ? (i + 2 * step) * tile_stride : tile);
 
     f32x16 acc[kQB];
 #pragma unroll
@@ -232,7 +250,7 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
       } else {
         asm volatile("" ::"v"(a));
       }
-      if (s % (KS / PPW) == 1 && has_next) issue_piece(next_rsrc, buf ^ 1, s / (KS / PPW));
+      if (s % (KS / PPW) == 1 && has_next2) issue_piece(next_rsrc, buf2, s / (KS / PPW));
       a0 = a1;
       a1 = a2;
     }
@@ -253,13 +271,11 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
       if (DEWI_MFMA_ABLATE == 1) {
         asm volatile("" ::"v"(acc[b]));
       } else if constexpr (DENSE) {
-        const int q = 32 * kQB * wave + 32 * b + r;
+        // sample pass: plain fp32 scores (rows past the corpus end were set to -inf above)
+        float* dense = reinterpret_cast<float*>(out) + static_cast<int64_t>(32 * kQB * wave + 32 * b + r) * out_stride +
+                       i * kTileRows + 4 * h;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int local = (j & 3) + 8 * (j >> 2) + 4 * h;
-          out[static_cast<int64_t>(q) * out_stride + i * kTileRows + local] =
-              row0 + local < n_rows ? make_key(acc[b][j], static_cast<uint32_t>(row0 + local)) : kKeyEmpty;
-        }
+        for (int j = 0; j < 16; ++j) dense[(j & 3) + 8 * (j >> 2)] = acc[b][j];
       } else {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -282,8 +298,8 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
       }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) a_addr[j] = buf ? a_addr[j] - TILE_BYTES : a_addr[j] + TILE_BYTES;
-    buf ^= 1;
+    for (int j = 0; j < 8; ++j) a_addr[j] = buf == kTileBufs - 1 ? a_addr[j] - (kTileBufs - 1) * TILE_BYTES : a_addr[j] + TILE_BYTES;
+    buf = buf == kTileBufs - 1 ? 0 : buf + 1;
   }
   if constexpr (!DENSE) {
 #pragma unroll
@@ -295,16 +311,61 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
 #endif
 }
 
-// Per-query threshold from the dense sample keys: the score of the c-th best sample document is a
-// lower bound of the query's final c-th best score.  One workgroup per query.
-__global__ __launch_bounds__(kSelectThreads) void sample_threshold_kernel(const uint64_t* __restrict__ dense,
+// Per-query threshold from the dense sample scores: the score of the c-th best sample document is a
+// lower bound of the query's final c-th best score.  One workgroup per query; exact 3-pass MSB radix
+// select (11 + 11 + 10 bits) on the order-preserving keys of the n_sample fp32 scores.
+__global__ __launch_bounds__(kSelectThreads) void sample_threshold_kernel(const float* __restrict__ dense,
                                                                           int64_t n_sample, int64_t stride,
                                                                           int n_candidates, float* __restrict__ thr) {
-  __shared__ SelectShared sh;
-  const int q = static_cast<int>(blockIdx.x);
-  const uint64_t key = block_kth_largest(ArrayKeys{dense + static_cast<int64_t>(q) * stride, n_sample},
-                                         static_cast<uint32_t>(n_candidates), sh);
-  if (threadIdx.x == 0) thr[q] = key <= 1ull ? -__builtin_inff() : key_score(key);
+  constexpr int kBins = 2048;
+  __shared__ uint32_t hist[kBins];
+  __shared__ uint32_t wave_tot[kSelectThreads / kWave];
+  __shared__ uint32_t pick_digit, pick_above, total;
+  const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
+  const int lane = tid & 63, wave = tid >> 6, n_waves = nt >> 6;
+  const float* s = dense + static_cast<int64_t>(blockIdx.x) * stride;
+  uint32_t prefix = 0, remaining = static_cast<uint32_t>(n_candidates);
+  for (int pass = 0; pass < 3; ++pass) {
+    const int bits = pass == 2 ? 10 : 11;
+    const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
+    for (int b = tid; b < kBins; b += nt) hist[b] = 0;
+    __syncthreads();
+    for (int64_t i = tid; i < n_sample; i += nt) {
+      const uint32_t key = ord_f32(s[i]);
+      if (pass == 0 || (key >> (shift + bits)) == prefix) atomicAdd(&hist[(key >> shift) & ((1u << bits) - 1u)], 1u);
+    }
+    __syncthreads();
+    // suffix sums: thread t owns bins 2t and 2t+1
+    const uint32_t h0 = 2 * tid < kBins ? hist[2 * tid] : 0u, h1 = 2 * tid + 1 < kBins ? hist[2 * tid + 1] : 0u;
+    uint32_t sfx = h0 + h1;
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t o = __shfl_down(sfx, off, kWave);
+      if (lane + off < 64) sfx += o;
+    }
+    if (lane == 0) wave_tot[wave] = sfx;
+    __syncthreads();
+    uint32_t above = 0;
+    for (int w = wave + 1; w < n_waves; ++w) above += wave_tot[w];
+    const uint32_t incl1 = sfx + above - h0;  // keys with digit >= 2t+1
+    const uint32_t incl0 = sfx + above;       // keys with digit >= 2t
+    if (tid == 0) total = incl0;
+    if (incl1 >= remaining && incl1 - h1 < remaining) {
+      pick_digit = 2 * tid + 1;
+      pick_above = incl1 - h1;
+    } else if (incl0 >= remaining && incl1 < remaining) {
+      pick_digit = 2 * tid;
+      pick_above = incl1;
+    }
+    __syncthreads();
+    if (total < remaining) {  // fewer sample scores than candidates (first pass only): no bound
+      if (tid == 0) thr[blockIdx.x] = -__builtin_inff();
+      return;
+    }
+    prefix = (prefix << bits) | pick_digit;
+    remaining -= pick_above;
+    __syncthreads();
+  }
+  if (tid == 0) thr[blockIdx.x] = unord_f32(prefix);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -335,7 +396,7 @@ MfmaLayout plan_mfma(int64_t n_rows, int dim, int n_queries, int n_candidates, i
   m.qb_off = off;      off += up(static_cast<size_t>(m.q_pad) * dim * 2);
   m.thr_off = off;     off += up(static_cast<size_t>(m.q_pad) * 4);
   m.cnt_off = off;     off += up(static_cast<size_t>(m.groups) * m.n_seg * kQueriesPerPass * 4);
-  m.dense_off = off;   off += up(static_cast<size_t>(kQueriesPerPass) * m.sample_stride * 8);
+  m.dense_off = off;   off += up(static_cast<size_t>(kQueriesPerPass) * m.sample_stride * 4);
   m.cand_off = off;    off += up(static_cast<size_t>(m.groups) * m.n_seg * kQueriesPerPass * m.seg_cap * 8);
   m.total = off;
   return m;
@@ -345,7 +406,7 @@ template <int KS>
 static hipError_t run_mfma_dim(const MfmaLayout& m, const uint16_t* E, int64_t n_rows, int n_candidates, char* ws,
                                int compute_units, hipStream_t stream) {
   constexpr int DIM = KS * 16;
-  const int lds_bytes = 2 * kTileRows * DIM * 2;
+  const int lds_bytes = kTileBufs * kTileRows * DIM * 2;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan_bf16<KS, true>),
@@ -359,7 +420,7 @@ static hipError_t run_mfma_dim(const MfmaLayout& m, const uint16_t* E, int64_t n
   const uint16_t* qb = reinterpret_cast<const uint16_t*>(ws + m.qb_off);
   float* thr = reinterpret_cast<float*>(ws + m.thr_off);
   uint32_t* cnt = reinterpret_cast<uint32_t*>(ws + m.cnt_off);
-  uint64_t* dense = reinterpret_cast<uint64_t*>(ws + m.dense_off);
+  float* dense = reinterpret_cast<float*>(ws + m.dense_off);
   uint64_t* cand = reinterpret_cast<uint64_t*>(ws + m.cand_off);
   for (int g = 0; g < m.groups; ++g) {
     const uint16_t* qg = qb + static_cast<int64_t>(g) * kQueriesPerPass * DIM;
@@ -370,7 +431,7 @@ static hipError_t run_mfma_dim(const MfmaLayout& m, const uint16_t* E, int64_t n
     const int sample_blocks = m.n_sample_tiles < compute_units ? static_cast<int>(m.n_sample_tiles) : compute_units;
     hipLaunchKernelGGL((mfma_scan_bf16<KS, true>), dim3(sample_blocks), dim3(kMfmaThreads), lds_bytes, stream, E, n_rows,
                        qg, m.n_sample_tiles, static_cast<int64_t>(kSampleStride), static_cast<const float*>(nullptr),
-                       dense, m.sample_stride, static_cast<uint32_t*>(nullptr));
+                       reinterpret_cast<uint64_t*>(dense), m.sample_stride, static_cast<uint32_t*>(nullptr));
     // 2. per-query threshold
     hipLaunchKernelGGL(sample_threshold_kernel, dim3(kQueriesPerPass), dim3(kSelectThreads), 0, stream, dense,
                        m.sample_stride, m.sample_stride, n_candidates, tg);

@@ -99,6 +99,7 @@ struct SegmentLayout {
   int raw;               // 1: entries are raw records (row << 32 | fp32 score bits), not ordered keys
   int64_t seg_stride;    // keys between consecutive segments (= queries_per_pass * cap)
   int64_t count_stride;  // counts between consecutive segments (= queries_per_pass)
+  int lds_keys;          // records the select kernel may stage in dynamic LDS (0: read segments in place)
 };
 hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, int sorted_lists, int n_queries,
                                 int n_candidates, int k, const RerankParams& rp, const float* d_dewi32, const float* d_ent32,

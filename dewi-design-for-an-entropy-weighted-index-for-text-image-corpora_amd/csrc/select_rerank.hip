@@ -96,6 +96,13 @@ __device__ int exact_top_candidates(const Keys& keys, int n_candidates, SelectSh
   });
   __syncthreads();
   const int n_sel = static_cast<int>(sh.count < static_cast<uint32_t>(n_candidates) ? sh.count : n_candidates);
+  if (n_sel <= kRankSortMax && sh.count <= static_cast<uint32_t>(kRankSortMax)) {
+    // exactly n_sel keys were gathered: one ranking pass instead of log^2 bitonic stages
+    for (int t = tid; t < n_sel; t += nt) sh.sel2[t] = sh.sel[t];
+    __syncthreads();
+    rank_sort_desc(sh.sel2, sh.sel, n_sel);
+    return n_sel;
+  }
   bitonic_sort_desc<false>(sh.sel, nullptr, p2);
   return n_sel;
 }
@@ -213,7 +220,22 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(
       return;
     }
     __syncthreads();
-    n_sel = exact_top_candidates(kv, n_candidates, sh);
+    // Gather the valid records of the hundreds of half-segments into LDS once; the radix-select
+    // passes then run over a dense LDS array instead of re-walking global memory five times.
+    extern __shared__ __attribute__((aligned(16))) uint64_t dyn_keys[];
+    if (tid == 0) sh.count = 0;
+    __syncthreads();
+    kv.for_each(tid, nt, [&](uint64_t key) {
+      const uint32_t pos = atomicAdd(&sh.count, 1u);
+      if (pos < static_cast<uint32_t>(seg.lds_keys)) dyn_keys[pos] = key;
+    });
+    __syncthreads();
+    const uint32_t total = sh.count;
+    __syncthreads();
+    if (total <= static_cast<uint32_t>(seg.lds_keys))
+      n_sel = exact_top_candidates(ArrayKeys{dyn_keys, static_cast<int64_t>(total)}, n_candidates, sh);
+    else
+      n_sel = exact_top_candidates(kv, n_candidates, sh);
   } else {
     n_sel = gather_top_candidates(keys, keys_per_query, sorted_lists, n_candidates, sh);
   }
@@ -380,7 +402,18 @@ hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, 
   } else if (keys_per_query <= 4096 && n_candidates <= 128) {
     threads = 256;
   }
-  hipLaunchKernelGGL(select_rerank_kernel, dim3(n_queries), dim3(threads), 0, stream, d_keys, keys_per_query,
+  size_t dyn = 0;
+  if (d_counts != nullptr && seg.lds_keys > 0) {
+    dyn = static_cast<size_t>(seg.lds_keys) * 8;
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&select_rerank_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      if (e != hipSuccess) return e;
+      attr_done = true;
+    }
+  }
+  hipLaunchKernelGGL(select_rerank_kernel, dim3(n_queries), dim3(threads), dyn, stream, d_keys, keys_per_query,
                      sorted_lists, n_candidates, k, rp, d_dewi32, d_ent32, id_offset, d_out_ids, d_out_scores,
                      d_out_cand, d_counts, seg);
   return hipGetLastError();
