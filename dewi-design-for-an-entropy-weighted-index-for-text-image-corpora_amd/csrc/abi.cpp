@@ -168,9 +168,11 @@ int check_common(const void* d_E, int64_t n_rows, int dim, const float* d_Q, int
   return DEWI_OK;
 }
 
+// n_candidates_override <= 0: the reference's cut, min(2k, n_rows) (backends.py:439).
 int knn_rerank_impl(const void* d_E, int elem_type, int64_t n_rows, int dim, const float* d_Q, int n_queries,
                     const float* d_dewi32, const float* d_ent32, int k, double eta, double pref, int space,
-                    int64_t* d_out_ids, float* d_out_scores, void* d_ws, size_t ws_bytes, void* stream_) {
+                    int64_t* d_out_ids, float* d_out_scores, void* d_ws, size_t ws_bytes, void* stream_,
+                    int n_candidates_override = 0) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   int rc = check_common(d_E, n_rows, dim, d_Q, n_queries, space);
   if (rc) return rc;
@@ -179,7 +181,12 @@ int knn_rerank_impl(const void* d_E, int elem_type, int64_t n_rows, int dim, con
     return fail(DEWI_ERR_K_OUT_OF_BOUNDS, "kth(=%lld) out of bounds (%lld)", static_cast<long long>(n_rows - k),
                 static_cast<long long>(n_rows));
   if (!d_dewi32 || !d_ent32 || !d_out_ids || !d_out_scores) return fail(DEWI_ERR_INVALID_ARG, "null payload or output pointer");
-  const int64_t c64 = (2ll * k < n_rows) ? 2ll * k : n_rows;
+  int64_t c64 = (2ll * k < n_rows) ? 2ll * k : n_rows;
+  if (n_candidates_override > 0) {
+    if (n_candidates_override < k)
+      return fail(DEWI_ERR_INVALID_ARG, "n_candidates %d must be at least k = %d", n_candidates_override, k);
+    c64 = n_candidates_override < n_rows ? n_candidates_override : n_rows;
+  }
   if (c64 > (1ll << 30)) return fail(DEWI_ERR_UNSUPPORTED, "candidate count %lld exceeds 2^30", static_cast<long long>(c64));
   const int c = static_cast<int>(c64);
   DeviceInfo dev;
@@ -306,6 +313,15 @@ int dewi_knn_rerank_f32(const float* d_E, int64_t n_rows, int dim, const float* 
                         void* stream) {
   return knn_rerank_impl(d_E, 0, n_rows, dim, d_Q, n_queries, d_dewi32, d_ent32, k, eta, entropy_pref, space,
                          d_out_ids, d_out_scores, d_workspace, workspace_bytes, stream);
+}
+
+int dewi_knn_rerank_candidates(const void* d_E, int elem_type, int64_t n_rows, int dim, const float* d_Q, int n_queries,
+                               const float* d_dewi32, const float* d_ent32, int k, int n_candidates, double eta,
+                               double entropy_pref, int space, int64_t* d_out_ids, float* d_out_scores,
+                               void* d_workspace, size_t workspace_bytes, void* stream) {
+  if (n_candidates <= 0) return fail(DEWI_ERR_INVALID_ARG, "n_candidates must be positive (got %d)", n_candidates);
+  return knn_rerank_impl(d_E, elem_type, n_rows, dim, d_Q, n_queries, d_dewi32, d_ent32, k, eta, entropy_pref, space,
+                         d_out_ids, d_out_scores, d_workspace, workspace_bytes, stream, n_candidates);
 }
 
 int dewi_knn_scan(const void* d_E, int elem_type, int64_t n_rows, int dim, const float* d_Q, int n_queries,

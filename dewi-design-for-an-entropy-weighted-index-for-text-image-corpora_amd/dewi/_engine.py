@@ -142,10 +142,13 @@ class DeviceCorpus:
         return self._q_dev
 
     # ------------------------------------------------------------------ hot path
-    def search_device(self, q_dev, k: int, eta: float, entropy_pref: float, out_ids=None, out_scores=None):
+    def search_device(self, q_dev, k: int, eta: float, entropy_pref: float, out_ids=None, out_scores=None,
+                      candidates: Optional[int] = None):
         """Enqueue one search on the current stream; returns device tensors, no sync.
 
         q_dev: fp32 [B, d] on this device (raw queries; cosine normalisation happens in-kernel).
+        ``candidates``: size of the similarity cut that is re-ranked; default min(2k, N) as the
+        reference's ExactIndex, ``candidates=k`` gives the rule of its HNSW / FAISS backends.
         """
         torch = _torch()
         b = int(q_dev.shape[0])
@@ -155,26 +158,32 @@ class DeviceCorpus:
         if k <= 0:
             return (torch.empty((b, 0), dtype=torch.int64, device=self.device),
                     torch.empty((b, 0), dtype=torch.float32, device=self.device))
-        c = min(2 * k, self.n_rows)
+        c = min(2 * k, self.n_rows) if candidates is None else min(int(candidates), self.n_rows)
         if out_ids is None:
             out_ids = torch.empty((b, k), dtype=torch.int64, device=self.device)
         if out_scores is None:
             out_scores = torch.empty((b, k), dtype=torch.float32, device=self.device)
         ws = self._workspace(b, max(c, 1))
-        fn = self._lib.dewi_knn_rerank_bf16 if self.is_bf16 else self._lib.dewi_knn_rerank_f32
-        rc = fn(nat.ptr(self.emb), self.n_rows, self.dim, nat.ptr(q_dev), b, nat.ptr(self.dewi32), nat.ptr(self.ent32),
-                k, float(eta), float(entropy_pref), nat.SPACE_CODES[self.space], nat.ptr(out_ids), nat.ptr(out_scores),
-                nat.ptr(ws), ws.numel(), nat.stream_ptr())
+        if candidates is None:
+            fn = self._lib.dewi_knn_rerank_bf16 if self.is_bf16 else self._lib.dewi_knn_rerank_f32
+            rc = fn(nat.ptr(self.emb), self.n_rows, self.dim, nat.ptr(q_dev), b, nat.ptr(self.dewi32),
+                    nat.ptr(self.ent32), k, float(eta), float(entropy_pref), nat.SPACE_CODES[self.space],
+                    nat.ptr(out_ids), nat.ptr(out_scores), nat.ptr(ws), ws.numel(), nat.stream_ptr())
+        else:
+            rc = self._lib.dewi_knn_rerank_candidates(
+                nat.ptr(self.emb), 1 if self.is_bf16 else 0, self.n_rows, self.dim, nat.ptr(q_dev), b, nat.ptr(self.dewi32),
+                nat.ptr(self.ent32), k, int(candidates), float(eta), float(entropy_pref), nat.SPACE_CODES[self.space],
+                nat.ptr(out_ids), nat.ptr(out_scores), nat.ptr(ws), ws.numel(), nat.stream_ptr())
         nat.check(rc)
         return out_ids, out_scores
 
-    def search(self, queries: ArrayLike, k: int = 10, eta: float = 0.5, entropy_pref: float = 0.0
-               ) -> Tuple[np.ndarray, np.ndarray]:
+    def search(self, queries: ArrayLike, k: int = 10, eta: float = 0.5, entropy_pref: float = 0.0,
+               candidates: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
         """Blocking convenience: (ids int64 [B,k] including id_offset, scores fp32 [B,k]) on the host."""
         torch = _torch()
         with torch.cuda.device(self.device):
             q = self.stage_queries(queries)
-            ids, scores = self.search_device(q, k, eta, entropy_pref)
+            ids, scores = self.search_device(q, k, eta, entropy_pref, candidates=candidates)
             ids_h = ids.cpu().numpy()
             scores_h = scores.cpu().numpy()
             # The batched bf16 matrix-core path marks a query whose candidate buffer overflowed
@@ -185,7 +194,7 @@ class DeviceCorpus:
                 for s0 in range(0, len(redo), 8):
                     sel = redo[s0:s0 + 8]
                     sub = q[torch.from_numpy(sel).to(q.device)].contiguous()
-                    i2, s2 = self.search_device(sub, k, eta, entropy_pref)
+                    i2, s2 = self.search_device(sub, k, eta, entropy_pref, candidates=candidates)
                     ids_h[sel] = i2.cpu().numpy()
                     scores_h[sel] = s2.cpu().numpy()
         if self.id_offset:

@@ -261,12 +261,18 @@ class ExactIndex(BaseIndex):
         if self._corpus is None or self._pending or not self._is_trained:
             self.build()
 
-    def search(self, query: np.ndarray, k: int = 10, eta: float = 0.5, entropy_pref: float = 0.0) -> SearchResult:
-        """Reference ``ExactIndex.search`` (backends.py:414-481) for one query."""
+    def search(self, query: np.ndarray, k: int = 10, eta: float = 0.5, entropy_pref: float = 0.0,
+               candidates: Optional[int] = None) -> SearchResult:
+        """Reference ``ExactIndex.search`` (backends.py:414-481) for one query.
+
+        ``candidates`` (additive): how many nearest rows are re-ranked.  Default ``min(2k, N)``, the
+        reference's ExactIndex rule; ``candidates=k`` is the rule of its HNSW / FAISS backends
+        (backends.py:217-240, 326-356: exactly k neighbours are blended and sorted) on exact neighbours.
+        """
         q = np.asarray(query, dtype=np.float32)
         if q.ndim == 1:
             q = q.reshape(1, -1)
-        rows, scores = self.search_batch(q, k, eta, entropy_pref)
+        rows, scores = self.search_batch(q, k, eta, entropy_pref, candidates)
         ids, pay = self._doc_ids, self._payloads
         out: SearchResult = []
         for r, s in zip(rows[0].tolist(), scores[0].tolist()):
@@ -274,14 +280,14 @@ class ExactIndex(BaseIndex):
             out.append((doc_id, float(s), pay[doc_id]))
         return out
 
-    def search_batch(self, queries: np.ndarray, k: int = 10, eta: float = 0.5, entropy_pref: float = 0.0
-                     ) -> Tuple[np.ndarray, np.ndarray]:
+    def search_batch(self, queries: np.ndarray, k: int = 10, eta: float = 0.5, entropy_pref: float = 0.0,
+                     candidates: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
         """[B, dim] queries -> (row indices int64 [B, k], adjusted scores fp32 [B, k])."""
         self._ensure_built()
         q = np.asarray(queries, dtype=np.float32)
         if q.ndim != 2 or q.shape[1] != self.dim:
             raise ValueError(f"Expected queries of shape (B, {self.dim}), got {q.shape}")
-        return self._corpus.search(q, int(k), float(eta), float(entropy_pref))
+        return self._corpus.search(q, int(k), float(eta), float(entropy_pref), candidates=candidates)
 
     def results_for(self, rows: np.ndarray, scores: np.ndarray) -> List[SearchResult]:
         """Row indices/scores of ``search_batch`` -> the reference's (doc_id, score, Payload) tuples."""

@@ -110,6 +110,15 @@ int dewi_knn_rerank_f32(const float* d_E, int64_t n_rows, int dim, const float* 
                         int space, int64_t* d_out_ids, float* d_out_scores, void* d_workspace,
                         size_t workspace_bytes, void* stream);
 
+/* A10 / F4  the same search with an explicit candidate count instead of min(2k, n_rows): n_candidates =
+ * k reproduces the re-rank rule of the reference's HNSWIndex / FAISSIndex.search (backends.py:204-241,
+ * 309-356: the library returns exactly k neighbours, which are then blended and sorted) on top of an
+ * exact neighbour search.  k <= n_candidates; elem_type 0 fp32, 1 bf16. */
+int dewi_knn_rerank_candidates(const void* d_E, int elem_type, int64_t n_rows, int dim, const float* d_Q, int n_queries,
+                               const float* d_dewi32, const float* d_ent32, int k, int n_candidates, double eta,
+                               double entropy_pref, int space, int64_t* d_out_ids, float* d_out_scores,
+                               void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* The same search split at the kernel boundary, for callers that keep several queries in flight:
  * dewi_knn_scan enqueues steps 1-3a (corpus scan, per-workgroup candidate lists -> workspace) and
  * dewi_knn_finish steps 3b-5 (select, blend, top-k) from that workspace.  The two may be enqueued on

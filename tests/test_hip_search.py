@@ -279,3 +279,27 @@ def test_pipelined_searcher_equals_serial_search():
     pipe2.drain()
     want = c.candidates_device(Q, 2 * k)
     assert torch.equal(recs[:, 0], want)
+
+
+def test_ann_semantics_candidates_equal_k():
+    """F4 / A10: candidates=k re-ranks exactly the k nearest rows (the HNSW / FAISS backends' rule,
+    reference backends.py:217-240) — checked against the oracle's ann_rerank on exact neighbours."""
+    n, d, k, eta, pref = 4000, 128, 10, 0.4, 0.2
+    raw = orc.synth_corpus(n, d, seed=21)
+    cols = orc.synth_payload_columns(n, seed=21)
+    Q = orc.synth_queries(6, d, seed=22)
+    c = _corpus(raw, cols)
+    E = c.emb.cpu().numpy()
+    ids, sc = c.search(Q, k, eta, pref, candidates=k)
+    ids2k, _ = c.search(Q, k, eta, pref)
+    assert not np.array_equal(ids, ids2k)                       # a different rule than the 2k cut
+    for j in range(Q.shape[0]):
+        s = orc.similarities(E, orc.prepare_query(Q[j]))
+        nn = np.argsort(-s.astype(np.float64), kind="stable")[:k]
+        want_ids, want_sc = orc.ann_rerank(nn, s[nn].astype(np.float64), cols["dewi"], cols["ht_mean"], cols["hi_mean"],
+                                           eta, pref)
+        assert sorted(ids[j].tolist()) == sorted(nn.tolist())   # exactly the k nearest rows
+        assert np.array_equal(ids[j], want_ids), j
+        assert np.allclose(sc[j], want_sc, atol=1e-5)
+    with pytest.raises(ValueError, match="at least k"):
+        c.search(Q, k, eta, pref, candidates=k - 1)
