@@ -179,7 +179,8 @@ def main():
         nbuf = depth + 1
         fin = torch.cuda.Stream()
         torch.cuda.set_stream(fin)          # torch.distributed orders collectives against the current stream
-        pipe = eng.PipelinedSearcher(corpus, k, eta, 0.0, n_queries=B, n_candidates=c, finish_stream=fin)
+        pipe = eng.PipelinedSearcher(corpus, k, eta, 0.0, n_queries=B, n_candidates=c, finish_stream=fin,
+                                     depth=int(os.environ.get("DEWI_BENCH_WS_DEPTH", "4")))
         send = [torch.empty((B, c, 4), dtype=torch.int32, device=device) for _ in range(nbuf)]
         recv = [torch.empty((world, B, c, 4), dtype=torch.int32, device=device) for _ in range(nbuf)]
         send_flat = [t.view(-1) for t in send]

@@ -228,7 +228,7 @@ class PipelinedSearcher:
     """
 
     def __init__(self, corpus: DeviceCorpus, k: int, eta: float, entropy_pref: float, n_queries: int = 1,
-                 n_candidates: Optional[int] = None, finish_stream=None):
+                 n_candidates: Optional[int] = None, finish_stream=None, depth: int = 2):
         torch = _torch()
         self.corpus = corpus
         self.k, self.eta, self.pref, self.b = int(k), float(eta), float(entropy_pref), int(n_queries)
@@ -241,9 +241,10 @@ class PipelinedSearcher:
         with torch.cuda.device(corpus.device):
             self.scan_stream = torch.cuda.Stream()
             self.finish_stream = finish_stream if finish_stream is not None else torch.cuda.Stream()
-            self._ws = [torch.empty(need, dtype=torch.uint8, device=corpus.device) for _ in range(2)]
-            self._scan_done = [torch.cuda.Event() for _ in range(2)]
-            self._finish_done = [torch.cuda.Event() for _ in range(2)]
+            self.depth = max(2, int(depth))   # workspaces in rotation = scans that may run ahead of their finish
+            self._ws = [torch.empty(need, dtype=torch.uint8, device=corpus.device) for _ in range(self.depth)]
+            self._scan_done = [torch.cuda.Event() for _ in range(self.depth)]
+            self._finish_done = [torch.cuda.Event() for _ in range(self.depth)]
         self._i = 0
         self._elem = 1 if corpus.is_bf16 else 0
         self._space = nat.SPACE_CODES[corpus.space]
@@ -254,10 +255,10 @@ class PipelinedSearcher:
         """Enqueue one query batch.  Final results go to (out_ids, out_scores); with ``out_records``
         (int32 [B, c, 4]) the shard's candidate records are written instead."""
         i = self._i
-        slot = i & 1
+        slot = i % self.depth
         self._i = i + 1
         c = self.corpus
-        if i >= 2:
+        if i >= self.depth:
             self.scan_stream.wait_event(self._finish_done[slot])       # workspace `slot` is free again
         rc = self._lib.dewi_knn_scan(self._emb, self._elem, c.n_rows, c.dim, q_dev.data_ptr(), self.b, self.c,
                                      self._space, self._ws[slot].data_ptr(), self._need, self._s_scan)
