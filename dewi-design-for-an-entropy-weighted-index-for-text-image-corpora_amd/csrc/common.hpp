@@ -73,6 +73,32 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
   return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
 }
 
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#define DEWI_STEP(CTRL, MASK)                                                       \
+  {                                                                                 \
+    uint32_t o = static_cast<uint32_t>(dpp_i32<CTRL, MASK>(0, static_cast<int>(v))); \
+    v = o > v ? o : v;                                                              \
+  }
+  DEWI_STEP(0xB1, 0xF)
+  DEWI_STEP(0x4E, 0xF)
+  DEWI_STEP(0x124, 0xF)
+  DEWI_STEP(0x128, 0xF)
+  DEWI_STEP(0x142, 0xA)
+  DEWI_STEP(0x143, 0xC)
+#undef DEWI_STEP
+  return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
+}
+
+// Maximum of a 64-bit key over the wave (same value in every lane): high word first, then the
+// low word among the lanes that hold the maximum high word.
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+  const uint32_t hi = static_cast<uint32_t>(v >> 32);
+  const uint32_t mhi = wave_max_u32(hi);
+  const uint32_t lo = hi == mhi ? static_cast<uint32_t>(v) : 0u;
+  const uint32_t mlo = wave_max_u32(lo);
+  return (static_cast<uint64_t>(mhi) << 32) | mlo;
+}
+
 // Minimum of a 64-bit key over the wave: minimum high word first, then the minimum low word
 // among the lanes that hold it.  Returns the same value in every lane.
 __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {

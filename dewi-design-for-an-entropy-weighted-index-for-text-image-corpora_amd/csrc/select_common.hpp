@@ -14,6 +14,8 @@ struct SelectShared {
   uint32_t wave_tot[4];
   uint32_t pick_digit, pick_above, pick_count, total;
   uint32_t count;
+  uint32_t n_contrib;   // sorted-list route: lists that can hold a key at or above the bound
+  uint64_t bound;
 };
 
 // Descending bitonic sort of p2 (power of two) keys in LDS, optional 32-bit payload.

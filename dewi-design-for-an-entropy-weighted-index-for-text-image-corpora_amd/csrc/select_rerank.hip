@@ -119,6 +119,76 @@ __device__ int exact_top_candidates(const Keys& keys, int n_candidates, SelectSh
 __device__ int gather_top_candidates(const uint64_t* __restrict__ keys, int64_t keys_per_query, int sorted_lists,
                                      int n_candidates, SelectShared& sh) {
   const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
+  if (sorted_lists > 0 && sorted_lists <= 4 * kWave && n_candidates <= kWave) {
+    // Up to 256 lists (one per CU — the usual case) and c <= 64.  ANY lower bound of the c-th largest
+    // key works; it only has to be cheap and tight.  One wave: lane l loads the maxima of lists l,
+    // l+64, l+128, l+192 and keeps the largest; the c-th largest of those 64 LANE maxima (a subset
+    // of all maxima, so a valid bound, and at most a few ranks below the exact one) is found by
+    // ranking across the wave with 64 readlanes.  ~4 K cycles; ranking all 256 maxima against each
+    // other (65 K 64-bit compares on one CU) cost 11.6 K, pulling the c largest out one DPP
+    // wave-maximum at a time 14 K.
+    if (tid == 0) {
+      sh.n_contrib = 0;
+      sh.count = 0;
+    }
+    __syncthreads();
+    if (tid < kWave) {
+      uint64_t m[4];
+      uint64_t lane_max = kKeyEmpty;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int l = tid + kWave * u;
+        m[u] = l < sorted_lists ? keys[static_cast<int64_t>(l) * n_candidates] : kKeyEmpty;
+        lane_max = m[u] > lane_max ? m[u] : lane_max;
+      }
+      const uint32_t mh = static_cast<uint32_t>(lane_max >> 32), ml = static_cast<uint32_t>(lane_max);
+      int rank = 0;
+#pragma unroll
+      for (int j = 0; j < kWave; ++j) {
+        const uint64_t o = (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mh), j))) << 32) |
+                           static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ml), j));
+        rank += (o > lane_max || (o == lane_max && j < tid)) ? 1 : 0;
+      }
+      // the lane ranked c-th (0-based c-1) holds the bound — unless it is empty (fewer than c lists)
+      const unsigned long long who = __ballot(rank == n_candidates - 1);
+      uint64_t bound = 1ull;
+      if (who != 0ull) {
+        const int src = __ffsll(who) - 1;
+        bound = (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mh), src))) << 32) |
+                static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ml), src));
+        if (bound == kKeyEmpty) bound = 1ull;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (m[u] != kKeyEmpty && m[u] >= bound) sh.val[atomicAdd(&sh.n_contrib, 1u)] = static_cast<uint32_t>(tid + kWave * u);
+      }
+      if (tid == 0) sh.bound = bound;
+    }
+    __syncthreads();
+    const uint64_t bound = sh.bound;
+    for (int t = tid; t < static_cast<int>(sh.n_contrib); t += nt) {
+      const uint64_t* lst = keys + static_cast<int64_t>(sh.val[t]) * n_candidates;
+      for (int j = 0; j < n_candidates; ++j) {
+        const uint64_t key = lst[j];
+        if (key == kKeyEmpty || key < bound) break;
+        const uint32_t pos = atomicAdd(&sh.count, 1u);
+        if (pos < static_cast<uint32_t>(kMaxSortCandidates)) sh.sel2[pos] = key;
+      }
+    }
+    __syncthreads();
+    const int survivors = static_cast<int>(sh.count);
+    if (survivors <= kRankSortMax) {
+      rank_sort_desc(sh.sel2, sh.sel, survivors);
+      return survivors < n_candidates ? survivors : n_candidates;
+    }
+    if (survivors <= kMaxSortCandidates) {
+      const int p2 = pow2_at_least(survivors);
+      for (int t = tid; t < p2; t += nt) sh.sel[t] = t < survivors ? sh.sel2[t] : kKeyEmpty;
+      bitonic_sort_desc<false>(sh.sel, nullptr, p2);
+      return survivors < n_candidates ? survivors : n_candidates;
+    }
+    __syncthreads();  // more survivors than LDS holds (degenerate input): exact select at the bottom
+  } else
   if (sorted_lists > 0 && sorted_lists <= kMaxSortCandidates) {
     // list maxima (entry 0); entry 1 is loaded in the same round trip because the owner of a
     // contributing list almost always needs it a moment later
@@ -398,7 +468,7 @@ hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, 
                                 hipStream_t stream) {
   int threads = kSelectThreads;
   if (sorted_lists > 0) {
-    threads = sorted_lists <= 64 ? 256 : kSelectThreads;
+    threads = sorted_lists <= 4 * kWave ? 256 : kSelectThreads;  // <= 256 lists: one wave finds the bound
   } else if (keys_per_query <= 4096 && n_candidates <= 128) {
     threads = 256;
   }
