@@ -355,6 +355,7 @@ __global__ __launch_bounds__(kSelectThreads) void merge_rerank_kernel(const dewi
   const int p2 = pow2_at_least(m);
   if (tid == 0) sh.count = 0;
   __syncthreads();
+  const bool small = m <= kRankSortMax;   // the usual case (8 shards x 2k records): one ranking pass
   for (int t = tid; t < p2; t += nt) {
     uint64_t key = kKeyEmpty;
     uint32_t src = 0;
@@ -368,10 +369,29 @@ __global__ __launch_bounds__(kSelectThreads) void merge_rerank_kernel(const dewi
         atomicAdd(&sh.count, 1u);
       }
     }
-    sh.sel[t] = key;
-    sh.val[t] = src;
+    if (small) {
+      sh.sel2[t] = key;
+    } else {
+      sh.sel[t] = key;
+      sh.val[t] = src;
+    }
   }
-  bitonic_sort_desc<true>(sh.sel, sh.val, p2);
+  if (small) {
+    __syncthreads();
+    for (int t = tid; t < m; t += nt) {
+      const uint64_t mine = sh.sel2[t];
+      int rank = 0;
+      for (int j = 0; j < m; ++j) {
+        const uint64_t o = sh.sel2[j];
+        rank += (o > mine || (o == mine && j < t)) ? 1 : 0;
+      }
+      sh.sel[rank] = mine;
+      sh.val[rank] = static_cast<uint32_t>(t);
+    }
+    __syncthreads();
+  } else {
+    bitonic_sort_desc<true>(sh.sel, sh.val, p2);
+  }
   const int n_sel = static_cast<int>(sh.count < static_cast<uint32_t>(n_candidates) ? sh.count : n_candidates);
   auto fetch = [&](int t, float& dewi, float& ent, int64_t& id) {
     const int s = static_cast<int>(sh.val[t]);
