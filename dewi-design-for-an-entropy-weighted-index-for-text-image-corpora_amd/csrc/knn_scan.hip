@@ -50,7 +50,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_rows_f32(const float* __res
                                                               int64_t keys_per_query) {
   constexpr int D4 = 64 * U;  // float4 units per row
   constexpr bool DENSE = S == 0;
-  __shared__ uint64_t merge_buf[S == 1 ? kScanThreads : 1];
+  __shared__ MergeShared merge_buf;
   const int lane = lane_id();
   const int wave_in_block = static_cast<int>(threadIdx.x) >> 6;
   const int64_t gwave = static_cast<int64_t>(blockIdx.x) * (kScanThreads / kWave) + wave_in_block;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_generic_f32(const float* __
                                                                  int64_t keys_per_query) {
   using V = typename VecT<VEC>::type;
   constexpr bool DENSE = S == 0;
-  __shared__ uint64_t merge_buf[S == 1 ? kScanThreads : 1];
+  __shared__ MergeShared merge_buf;
   const int lane = lane_id();
   const int wave_in_block = static_cast<int>(threadIdx.x) >> 6;
   const int64_t gwave = static_cast<int64_t>(blockIdx.x) * (kScanThreads / kWave) + wave_in_block;

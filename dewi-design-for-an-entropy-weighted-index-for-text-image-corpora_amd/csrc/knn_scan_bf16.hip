@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_rows_bf16(const uint16_t* _
   constexpr int D = 256 * H;          // columns
   constexpr int UPR = 32 * H;         // 16-byte units per row
   constexpr bool DENSE = S == 0;
-  __shared__ uint64_t merge_buf[S == 1 ? kScanThreads : 1];
+  __shared__ MergeShared merge_buf;
   const int lane = lane_id();
   const int wave_in_block = static_cast<int>(threadIdx.x) >> 6;
   const int64_t gwave = static_cast<int64_t>(blockIdx.x) * (kScanThreads / kWave) + wave_in_block;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_generic_bf16(const uint16_t
                                                                   int n_candidates, uint64_t* __restrict__ keys,
                                                                   int64_t keys_per_query) {
   constexpr bool DENSE = S == 0;
-  __shared__ uint64_t merge_buf[S == 1 ? kScanThreads : 1];
+  __shared__ MergeShared merge_buf;
   const int lane = lane_id();
   const int wave_in_block = static_cast<int>(threadIdx.x) >> 6;
   const int64_t gwave = static_cast<int64_t>(blockIdx.x) * (kScanThreads / kWave) + wave_in_block;
