@@ -195,68 +195,9 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
 #pragma unroll
     for (int i = 0; i < PPW; ++i) issue_piece(rs, 1, i);
   }
-  int buf = 0;
-  for (int64_t i = first; i < n_tiles; i += step) {
-    const int64_t tile = i * tile_stride;
-    // tile i+2 is fetched while tile i is multiplied: a tile has two whole iterations to land
-    const bool has_next2 = (i + 2 * step < n_tiles) && DEWI_MFMA_ABLATE != 2;
-    const bool has_next1 = (i + step < n_tiles) && DEWI_MFMA_ABLATE != 2;
-    // Outstanding, oldest first: this tile's pieces, the next tile's pieces (issued during the previous
-    // matrix block), then the previous epilogue's few survivor stores.  Leaving the PPW youngest
-    // operations in flight therefore guarantees this tile has landed (it over-waits by one piece per
-    // survivor store, which is harmless).
-    if (has_next1) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();   // (a) every wave's pieces of this tile have landed
-                                    // (b) every wave has finished reading the slot of tile i-1, which
-                                    //     the DMA of tile i+2 (issued below) refills
-    asm volatile("" ::: "memory");
-    const int buf2 = buf + 2 >= kTileBufs ? buf + 2 - kTileBufs : buf + 2;
-    const __amdgpu_buffer_rsrc_t next_rsrc = tile_rsrc(has_next2 ? (i + 2 * step) * tile_stride : tile);
-
-    f32x16 acc[kQB];
-#pragma unroll
-    for (int b = 0; b < kQB; ++b) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) acc[b][j] = 0.f;
-    }
-    // A fragments are read two k-steps ahead of the MFMAs that consume them (each feeds two MFMAs,
-    // 64 cycles of matrix work per read).  hipcc sinks plain LDS loads back next to their use at this
-    // register pressure, so the reads and their counted waits are inline asm: LDS returns data in
-    // order, hence before step s may start at most the two younger reads (s+1, s+2) may be pending.
-    // The wait statement takes the fragment as an in/out operand so that the MFMAs cannot be
-    // scheduled above it.  No other LGKM operation is issued inside this block.  The next tile's DMA
-    // pieces are issued one per KS/PPW k-steps, in the shadow of the MFMAs.
-    u32x4m a0, a1, a2;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(a0) : "v"(a_addr[0]));
-    asm volatile("ds_read_b128 %0, %1" : "=v"(a1) : "v"(a_addr[1]));
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      if (s + 2 < KS) {
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a2) : "v"(a_addr[(s + 2) & 7]), "n"(256 * ((s + 2) >> 3)));
-        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a0));
-      } else if (s + 1 < KS) {
-        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a0));
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0));
-      }
-      const bf16x8 a = __builtin_bit_cast(bf16x8, a0);
-      if (DEWI_MFMA_ABLATE != 3) {
-#pragma unroll
-        for (int b = 0; b < kQB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[b][s], acc[b], 0, 0, 0);
-      } else {
-        asm volatile("" ::"v"(a));
-      }
-      if (s % (KS / PPW) == 1 && has_next2) issue_piece(next_rsrc, buf2, s / (KS / PPW));
-      a0 = a1;
-      a1 = a2;
-    }
-
-    // ---- epilogue: D[doc = (j&3) + 8*(j>>2) + 4*h][query = 64*wave + 32*b + r]
-    const int64_t row0 = tile * kTileRows;
+  // The epilogue of tile i: D[doc = (j&3) + 8*(j>>2) + 4*h][query = 32*wave + r].
+  auto epilogue = [&](f32x16 (&acc)[kQB], int64_t i) {
+    const int64_t row0 = i * tile_stride * kTileRows;
     const int doc0 = static_cast<int>(row0) + 4 * h;           // n_rows < 2^32 and row0 < n_rows
     if (row0 + kTileRows > n_rows) {                           // partial last tile: padding rows never pass
 #pragma unroll
@@ -297,10 +238,81 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
         }
       }
     }
+  };
+  // The two waves of a SIMD run half a period apart: waves 0..NW/2-1 multiply tile i and then
+  // filter it; waves NW/2.. filter tile i-1 FIRST and multiply tile i afterwards.  One wave of each
+  // SIMD is therefore in its matrix block while the other is in its (matrix-pipe-idle) epilogue,
+  // instead of both competing for the pipe and then both leaving it idle.
+  const bool deferred = wave_u >= NW / 2;
+  f32x16 acc[kQB];
+  int64_t prev = -1;
+  int buf = 0;
+  for (int64_t i = first; i < n_tiles; i += step) {
+    const int64_t tile = i * tile_stride;
+    // tile i+2 is fetched while tile i is multiplied: a tile has two whole iterations to land
+    const bool has_next2 = (i + 2 * step < n_tiles) && DEWI_MFMA_ABLATE != 2;
+    const bool has_next1 = (i + step < n_tiles) && DEWI_MFMA_ABLATE != 2;
+    // Outstanding, oldest first: this tile's pieces, the next tile's pieces (issued during the previous
+    // matrix block), then the previous epilogue's few survivor stores.  Leaving the PPW youngest
+    // operations in flight therefore guarantees this tile has landed (it over-waits by one piece per
+    // survivor store, which is harmless).
+    if (has_next1) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();   // (a) every wave's pieces of this tile have landed
+                                    // (b) every wave has finished reading the slot of tile i-1, which
+                                    //     the DMA of tile i+2 (issued below) refills
+    asm volatile("" ::: "memory");
+    const int buf2 = buf + 2 >= kTileBufs ? buf + 2 - kTileBufs : buf + 2;
+    const __amdgpu_buffer_rsrc_t next_rsrc = tile_rsrc(has_next2 ? (i + 2 * step) * tile_stride : tile);
+
+    if (deferred && prev >= 0) epilogue(acc, prev);
+#pragma unroll
+    for (int b = 0; b < kQB; ++b) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[b][j] = 0.f;
+    }
+    // A fragments are read two k-steps ahead of the MFMAs that consume them (each feeds two MFMAs,
+    // 64 cycles of matrix work per read).  hipcc sinks plain LDS loads back next to their use at this
+    // register pressure, so the reads and their counted waits are inline asm: LDS returns data in
+    // order, hence before step s may start at most the two younger reads (s+1, s+2) may be pending.
+    // The wait statement takes the fragment as an in/out operand so that the MFMAs cannot be
+    // scheduled above it.  No other LGKM operation is issued inside this block.  The next tile's DMA
+    // pieces are issued one per KS/PPW k-steps, in the shadow of the MFMAs.
+    u32x4m a0, a1, a2;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(a0) : "v"(a_addr[0]));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(a1) : "v"(a_addr[1]));
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if (s + 2 < KS) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a2) : "v"(a_addr[(s + 2) & 7]), "n"(256 * ((s + 2) >> 3)));
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a0));
+      } else if (s + 1 < KS) {
+        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a0));
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0));
+      }
+      const bf16x8 a = __builtin_bit_cast(bf16x8, a0);
+      if (DEWI_MFMA_ABLATE != 3) {
+#pragma unroll
+        for (int b = 0; b < kQB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[b][s], acc[b], 0, 0, 0);
+      } else {
+        asm volatile("" ::"v"(a));
+      }
+      if (s % (KS / PPW) == 1 && has_next2) issue_piece(next_rsrc, buf2, s / (KS / PPW));
+      a0 = a1;
+      a1 = a2;
+    }
+
+    if (!deferred) epilogue(acc, i);
+    prev = i;
 #pragma unroll
     for (int j = 0; j < 8; ++j) a_addr[j] = buf == kTileBufs - 1 ? a_addr[j] - (kTileBufs - 1) * TILE_BYTES : a_addr[j] + TILE_BYTES;
     buf = buf == kTileBufs - 1 ? 0 : buf + 1;
   }
+  if (deferred && prev >= 0) epilogue(acc, prev);
   if constexpr (!DENSE) {
 #pragma unroll
     for (int b = 0; b < kQB; ++b) {
