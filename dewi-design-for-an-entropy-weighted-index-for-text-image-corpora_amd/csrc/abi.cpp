@@ -451,6 +451,55 @@ int dewi_robust_fit_f32(const float* d_S, int64_t n, int64_t ld, int n_signals, 
   return e == hipSuccess ? DEWI_OK : hip_fail(e, "robust_fit launch");
 }
 
+// ---- sharded robust fit: the select of dewi_robust_fit_f32 split at its histogram boundaries ----
+static int check_fit_step(int n_signals, int phase, int pass, void* d_workspace, size_t workspace_bytes) {
+  if (n_signals <= 0) return fail(DEWI_ERR_INVALID_ARG, "n_signals %d", n_signals);
+  if (phase < 0 || phase > 1 || pass < 0 || pass > 2) return fail(DEWI_ERR_INVALID_ARG, "phase %d / pass %d out of range", phase, pass);
+  const size_t need = dewi::robust_fit_workspace_bytes(n_signals);
+  if (!d_workspace || workspace_bytes < need) return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, need);
+  return DEWI_OK;
+}
+
+int dewi_robust_fit_begin(int n_signals, void* d_workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_fit_step(n_signals, 0, 0, d_workspace, workspace_bytes)) return rc;
+  hipError_t e = dewi::launch_fit_begin(d_workspace, n_signals, static_cast<hipStream_t>(stream));
+  return e == hipSuccess ? DEWI_OK : hip_fail(e, "robust_fit_begin");
+}
+
+int dewi_robust_fit_hist_f32(const float* d_S, int64_t n_local, int64_t ld, int n_signals, int phase, int pass,
+                             const float* d_med, void* d_workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_fit_step(n_signals, phase, pass, d_workspace, workspace_bytes)) return rc;
+  if (n_local < 0 || ld < n_local) return fail(DEWI_ERR_INVALID_ARG, "bad shape n_local=%lld ld=%lld", static_cast<long long>(n_local), static_cast<long long>(ld));
+  if (n_local > 0 && !d_S) return fail(DEWI_ERR_INVALID_ARG, "null pointer");
+  if (phase == 1 && !d_med) return fail(DEWI_ERR_INVALID_ARG, "the MAD phase needs the medians");
+  if (n_local > 0xFFFFFFFFll) return fail(DEWI_ERR_UNSUPPORTED, "n exceeds 2^32-1");
+  hipError_t e = dewi::launch_fit_hist(d_S, n_local, ld, n_signals, phase, pass, d_med, d_workspace, static_cast<hipStream_t>(stream));
+  return e == hipSuccess ? DEWI_OK : hip_fail(e, "robust_fit_hist launch");
+}
+
+int dewi_robust_fit_region(int n_signals, int phase, int pass, int which, size_t* offset_bytes, size_t* count_u32) {
+  if (n_signals <= 0 || phase < 0 || phase > 1 || pass < 0 || pass > 2 || which < 0 || which > 1 || !offset_bytes || !count_u32)
+    return fail(DEWI_ERR_INVALID_ARG, "bad region request");
+  dewi::robust_fit_region(n_signals, phase, pass, which, offset_bytes, count_u32);
+  return DEWI_OK;
+}
+
+int dewi_robust_fit_pick(int64_t n_total, int n_signals, int phase, int pass, void* d_workspace, size_t workspace_bytes,
+                         void* stream) {
+  if (int rc = check_fit_step(n_signals, phase, pass, d_workspace, workspace_bytes)) return rc;
+  if (n_total <= 0 || n_total > 0xFFFFFFFFll) return fail(DEWI_ERR_INVALID_ARG, "n_total %lld", static_cast<long long>(n_total));
+  hipError_t e = dewi::launch_fit_pick(n_total, n_signals, phase, pass, d_workspace, static_cast<hipStream_t>(stream));
+  return e == hipSuccess ? DEWI_OK : hip_fail(e, "robust_fit_pick launch");
+}
+
+int dewi_robust_fit_finish(int64_t n_total, int n_signals, int phase, void* d_workspace, size_t workspace_bytes,
+                           float* d_out, void* stream) {
+  if (int rc = check_fit_step(n_signals, phase, 0, d_workspace, workspace_bytes)) return rc;
+  if (n_total <= 0 || !d_out) return fail(DEWI_ERR_INVALID_ARG, "bad arguments");
+  hipError_t e = dewi::launch_fit_finish(n_total, n_signals, phase, d_workspace, d_out, static_cast<hipStream_t>(stream));
+  return e == hipSuccess ? DEWI_OK : hip_fail(e, "robust_fit_finish launch");
+}
+
 int dewi_score_f64(const void* d_S, int signals_are_f64, int64_t n, int64_t ld, const double* med, const double* mad,
                    const double* weights, double delta, int mode, double* d_out, float* d_out32, void* stream) {
   if (!d_S || !med || !mad || !weights || !d_out) return fail(DEWI_ERR_INVALID_ARG, "null pointer");

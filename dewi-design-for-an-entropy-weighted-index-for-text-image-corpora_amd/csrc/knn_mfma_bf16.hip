@@ -8,6 +8,12 @@
 //
 // Roofline: co-limited.  Algorithmic bytes per pass = n_rows*dim*2 (HBM, read once); flops =
 // 2*256*n_rows*dim (393 GFLOP at C3) -> 256 flop/B against a ~310 flop/B machine balance.
+// What actually bounds this kernel is LDS bandwidth: with the queries resident in registers every
+// MFMA (32 matrix-pipe cycles) consumes one 1 KiB A fragment from LDS, and four SIMDs doing that
+// back to back ask for exactly the LDS peak (128 B/clk/CU).  Measured at C3: 344 us per pass; with
+// the MFMAs removed (LDS reads, DMA and epilogue only) 323 us; with the epilogue removed 302 us.
+// Two 32-query blocks per A fragment would halve the LDS traffic but need 384 query registers per
+// wave at dim 768 (4 waves x 512 registers: no second wave to cover the epilogue — measured 492 us).
 //
 // Structure (one 8-wave workgroup per CU, two waves per SIMD, persistent over 32-document tiles):
 //  * QUERIES LIVE IN REGISTERS.  Wave w owns queries 32w..32w+31 for the whole kernel: their B
@@ -29,8 +35,8 @@
 //    belongs to one wave and to two of its lanes, so the slot counter is a register and the record
 //    a fire-and-forget global store — no atomics, nothing that drains the DMA queue.  (Appending
 //    with returning global atomics: 1.85 ms per pass; LDS counters + per-element predication:
-//    0.54 ms, 1/3 of it epilogue.)  One v_cmp per accumulator register doubles as the wave-wide
-//    ballot, so registers without survivors cost a compare and a scalar branch.  If a half-segment
+//    0.54 ms, 1/3 of it epilogue.)  One v_cmp + execz branch per accumulator register: registers
+//    without survivors (most of them) cost a compare and a scalar branch.  If a half-segment
 //    overflows (only for adversarial corpora, e.g. tens of thousands of exact duplicates of a top
 //    document) its count keeps growing and the finish kernel flags the query.
 #include "select_common.hpp"
@@ -51,6 +57,7 @@ constexpr int kMfmaThreads = 64 * (8 / kQB);
 constexpr int kTileRows = 32;
 constexpr int kQueriesPerPass = 256;  // 8 waves x 32 (or 4 x 64)
 constexpr int kSampleStride = 32;     // every 32nd tile is a sample tile
+constexpr int kMaxStagedSample = 32 * 1024;  // sample scores per query the threshold kernel keeps in LDS (128 KiB)
 constexpr int kTileBufs = 3;          // LDS ring: the tile being multiplied + two tiles of DMA in flight
 #ifndef DEWI_MFMA_ABLATE
 #define DEWI_MFMA_ABLATE 0   // timing experiments only: 1 no epilogue, 2 no DMA after the first tile, 3 no MFMA
@@ -220,20 +227,18 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
       } else {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-          // one v_cmp per accumulator register; its result IS the wave-wide ballot, so registers in
-          // which no lane passes (most of them) cost one compare and one scalar branch
+          // one v_cmp + s_and_saveexec + s_cbranch_execz per accumulator register: registers in
+          // which no lane passes (most of them) fall straight through
           const bool pass = !(acc[b][j] < thr_l[b]);           // NaN passes (NumPy ranks NaN first)
-          if (__builtin_amdgcn_ballot_w64(pass) != 0ull) {
-            if (pass) {
-              const uint32_t seg_q = (static_cast<uint32_t>(blockIdx.x) * 2 + h) * kQueriesPerPass + (32 * kQB * wave + 32 * b + r);
-              if (slot[b] - seg_q * static_cast<uint32_t>(out_stride) < static_cast<uint32_t>(out_stride)) {
-                // raw record: high word = document row, low word = fp32 score bits (the finish kernel
-                // builds the ordered key)
-                out[slot[b]] = (static_cast<uint64_t>(static_cast<uint32_t>(doc0 + (j & 3) + 8 * (j >> 2))) << 32) |
-                               __float_as_uint(acc[b][j]);
-              }
-              ++slot[b];
+          if (pass) {
+            const uint32_t seg_q = (static_cast<uint32_t>(blockIdx.x) * 2 + h) * kQueriesPerPass + (32 * kQB * wave + 32 * b + r);
+            if (slot[b] - seg_q * static_cast<uint32_t>(out_stride) < static_cast<uint32_t>(out_stride)) {
+              // raw record: high word = document row, low word = fp32 score bits (the finish kernel
+              // builds the ordered key)
+              out[slot[b]] = (static_cast<uint64_t>(static_cast<uint32_t>(doc0 + (j & 3) + 8 * (j >> 2))) << 32) |
+                             __float_as_uint(acc[b][j]);
             }
+            ++slot[b];
           }
         }
       }
@@ -326,58 +331,100 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
 // Per-query threshold from the dense sample scores: the score of the c-th best sample document is a
 // lower bound of the query's final c-th best score.  One workgroup per query; exact 3-pass MSB radix
 // select (11 + 11 + 10 bits) on the order-preserving keys of the n_sample fp32 scores.
+//
+// The three passes are bound by reading the scores (256 queries x 31 K samples = 32 MB per pass,
+// more than the L2s hold): STAGED keeps the query's keys in LDS (n_sample <= 32 K: 125 KiB of the
+// 160) during the first pass — read from global once, with 16-byte loads — and passes 2 and 3 run
+// out of LDS.  (Tried and dropped: a floor from the c-th largest per-thread maximum to thin out the
+// first-pass LDS atomics — the extra read pass cost more than the atomics it saved, 53 vs 42 us.)
+struct RadixPick {
+  uint32_t prefix, remaining;
+  bool short_input;   // fewer keys than the wanted rank
+};
+
+// One radix pass over the histogram in LDS: finds the digit holding the `remaining`-th largest key.
+// Every thread returns the same values.  `hist` holds kBins counters.
+template <int kBins>
+__device__ __forceinline__ void pick_digit_desc(const uint32_t* hist, uint32_t* wave_tot, uint32_t* pick, int bits,
+                                                RadixPick& st) {
+  const int tid = static_cast<int>(threadIdx.x);
+  const int lane = tid & 63, wave = tid >> 6, n_waves = static_cast<int>(blockDim.x) >> 6;
+  // suffix sums: thread t owns bins 2t and 2t+1
+  const uint32_t h0 = 2 * tid < kBins ? hist[2 * tid] : 0u, h1 = 2 * tid + 1 < kBins ? hist[2 * tid + 1] : 0u;
+  uint32_t sfx = h0 + h1;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = __shfl_down(sfx, off, kWave);
+    if (lane + off < 64) sfx += o;
+  }
+  if (lane == 0) wave_tot[wave] = sfx;
+  __syncthreads();
+  uint32_t above = 0;
+  for (int w = wave + 1; w < n_waves; ++w) above += wave_tot[w];
+  const uint32_t incl1 = sfx + above - h0;  // keys with digit >= 2t+1
+  const uint32_t incl0 = sfx + above;       // keys with digit >= 2t
+  if (tid == 0) pick[2] = incl0;            // total
+  if (incl1 >= st.remaining && incl1 - h1 < st.remaining) {
+    pick[0] = 2 * tid + 1;
+    pick[1] = incl1 - h1;
+  } else if (incl0 >= st.remaining && incl1 < st.remaining) {
+    pick[0] = 2 * tid;
+    pick[1] = incl1;
+  }
+  __syncthreads();
+  if (pick[2] < st.remaining) {
+    st.short_input = true;
+  } else {
+    st.prefix = (st.prefix << bits) | pick[0];
+    st.remaining -= pick[1];
+  }
+  __syncthreads();
+}
+
+// n_sample % 4 == 0 and 16-byte aligned rows (the dense pass writes whole 32-document tiles).
+template <bool STAGED>
 __global__ __launch_bounds__(kSelectThreads) void sample_threshold_kernel(const float* __restrict__ dense,
                                                                           int64_t n_sample, int64_t stride,
                                                                           int n_candidates, float* __restrict__ thr) {
   constexpr int kBins = 2048;
+  extern __shared__ __attribute__((aligned(16))) uint32_t staged[];   // STAGED: n_sample keys
   __shared__ uint32_t hist[kBins];
   __shared__ uint32_t wave_tot[kSelectThreads / kWave];
-  __shared__ uint32_t pick_digit, pick_above, total;
+  __shared__ uint32_t pick[3];
+  typedef float f32x4s __attribute__((ext_vector_type(4)));
+  typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
   const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
-  const int lane = tid & 63, wave = tid >> 6, n_waves = nt >> 6;
-  const float* s = dense + static_cast<int64_t>(blockIdx.x) * stride;
-  uint32_t prefix = 0, remaining = static_cast<uint32_t>(n_candidates);
+  const f32x4s* s4 = reinterpret_cast<const f32x4s*>(dense + static_cast<int64_t>(blockIdx.x) * stride);
+  const int n4 = static_cast<int>(n_sample >> 2);
+  RadixPick st{0u, static_cast<uint32_t>(n_candidates), false};
   for (int pass = 0; pass < 3; ++pass) {
     const int bits = pass == 2 ? 10 : 11;
     const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
     for (int b = tid; b < kBins; b += nt) hist[b] = 0;
     __syncthreads();
-    for (int64_t i = tid; i < n_sample; i += nt) {
-      const uint32_t key = ord_f32(s[i]);
-      if (pass == 0 || (key >> (shift + bits)) == prefix) atomicAdd(&hist[(key >> shift) & ((1u << bits) - 1u)], 1u);
+#pragma unroll 2
+    for (int i = tid; i < n4; i += nt) {
+      u32x4s key;
+      if (STAGED && pass > 0) {
+        key = reinterpret_cast<const u32x4s*>(staged)[i];
+      } else {
+        const f32x4s v = s4[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) key[e] = ord_f32(v[e]);
+        if (STAGED) reinterpret_cast<u32x4s*>(staged)[i] = key;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (pass == 0 || (key[e] >> (shift + bits)) == st.prefix) atomicAdd(&hist[(key[e] >> shift) & ((1u << bits) - 1u)], 1u);
+      }
     }
     __syncthreads();
-    // suffix sums: thread t owns bins 2t and 2t+1
-    const uint32_t h0 = 2 * tid < kBins ? hist[2 * tid] : 0u, h1 = 2 * tid + 1 < kBins ? hist[2 * tid + 1] : 0u;
-    uint32_t sfx = h0 + h1;
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t o = __shfl_down(sfx, off, kWave);
-      if (lane + off < 64) sfx += o;
-    }
-    if (lane == 0) wave_tot[wave] = sfx;
-    __syncthreads();
-    uint32_t above = 0;
-    for (int w = wave + 1; w < n_waves; ++w) above += wave_tot[w];
-    const uint32_t incl1 = sfx + above - h0;  // keys with digit >= 2t+1
-    const uint32_t incl0 = sfx + above;       // keys with digit >= 2t
-    if (tid == 0) total = incl0;
-    if (incl1 >= remaining && incl1 - h1 < remaining) {
-      pick_digit = 2 * tid + 1;
-      pick_above = incl1 - h1;
-    } else if (incl0 >= remaining && incl1 < remaining) {
-      pick_digit = 2 * tid;
-      pick_above = incl1;
-    }
-    __syncthreads();
-    if (total < remaining) {  // fewer sample scores than candidates (first pass only): no bound
+    pick_digit_desc<kBins>(hist, wave_tot, pick, bits, st);
+    if (st.short_input) {  // fewer sample scores than candidates (first pass only): no bound
       if (tid == 0) thr[blockIdx.x] = -__builtin_inff();
       return;
     }
-    prefix = (prefix << bits) | pick_digit;
-    remaining -= pick_above;
-    __syncthreads();
   }
-  if (tid == 0) thr[blockIdx.x] = unord_f32(prefix);
+  if (tid == 0) thr[blockIdx.x] = unord_f32(st.prefix);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -427,6 +474,9 @@ static hipError_t run_mfma_dim(const MfmaLayout& m, const uint16_t* E, int64_t n
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan_bf16<KS, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sample_threshold_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kMaxStagedSample * 4);
+    if (e != hipSuccess) return e;
     attr_done = true;
   }
   const uint16_t* qb = reinterpret_cast<const uint16_t*>(ws + m.qb_off);
@@ -445,8 +495,13 @@ static hipError_t run_mfma_dim(const MfmaLayout& m, const uint16_t* E, int64_t n
                        qg, m.n_sample_tiles, static_cast<int64_t>(kSampleStride), static_cast<const float*>(nullptr),
                        reinterpret_cast<uint64_t*>(dense), m.sample_stride, static_cast<uint32_t*>(nullptr));
     // 2. per-query threshold
-    hipLaunchKernelGGL(sample_threshold_kernel, dim3(kQueriesPerPass), dim3(kSelectThreads), 0, stream, dense,
-                       m.sample_stride, m.sample_stride, n_candidates, tg);
+    if (m.sample_stride <= kMaxStagedSample)
+      hipLaunchKernelGGL(sample_threshold_kernel<true>, dim3(kQueriesPerPass), dim3(kSelectThreads),
+                         static_cast<size_t>(m.sample_stride) * 4, stream, dense, m.sample_stride, m.sample_stride,
+                         n_candidates, tg);
+    else
+      hipLaunchKernelGGL(sample_threshold_kernel<false>, dim3(kQueriesPerPass), dim3(kSelectThreads), 0, stream, dense,
+                         m.sample_stride, m.sample_stride, n_candidates, tg);
     // 3. full pass with the filter: n_blocks workgroups, each writing its own half-segments and counts
     hipLaunchKernelGGL((mfma_scan_bf16<KS, false>), dim3(m.n_blocks), dim3(kMfmaThreads), lds_bytes, stream, E, n_rows, qg,
                        m.n_tiles, static_cast<int64_t>(1), static_cast<const float*>(tg), og,

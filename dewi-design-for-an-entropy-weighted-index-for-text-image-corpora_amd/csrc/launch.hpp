@@ -125,6 +125,12 @@ hipError_t launch_payload_soa(const double* dewi, const double* ht, const double
 
 // ---- robust_stats.hip ---------------------------------------------------------------------
 size_t robust_fit_workspace_bytes(int n_signals);
+void robust_fit_region(int n_signals, int phase, int pass, int which, size_t* offset_bytes, size_t* count_u32);
+hipError_t launch_fit_begin(void* d_ws, int n_signals, hipStream_t stream);
+hipError_t launch_fit_hist(const float* S, int64_t n, int64_t ld, int n_signals, int phase, int pass, const float* med,
+                           void* d_ws, hipStream_t stream);
+hipError_t launch_fit_pick(int64_t n_total, int n_signals, int phase, int pass, void* d_ws, hipStream_t stream);
+hipError_t launch_fit_finish(int64_t n_total, int n_signals, int phase, void* d_ws, float* d_out, hipStream_t stream);
 hipError_t launch_robust_fit(const float* d_S, int64_t n, int64_t ld, int n_signals, float* d_med, float* d_mad,
                              void* d_ws, hipStream_t stream);
 struct ScoreParams {

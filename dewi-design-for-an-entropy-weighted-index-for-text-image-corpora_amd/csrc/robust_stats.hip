@@ -173,37 +173,84 @@ __global__ void fit_finish_kernel(const FitState* __restrict__ state, const uint
   out[s] = r;
 }
 
-template <bool MAD>
-static void run_phase(const float* S, int64_t n, int64_t ld, int n_signals, const float* med, FitWorkspace w,
-                      float* out, hipStream_t stream) {
-  const int phase = MAD ? 1 : 0;
+// ---- the select split at its histogram boundaries (also the pieces of the sharded fit: each rank
+// histograms its own rows, the caller sums the histogram region over ranks, every rank picks with the
+// global row count).
+static uint32_t* hist_of(const FitWorkspace& w, int n_signals, int phase, int pass) {
+  const int64_t P = 2 * n_signals;
+  return w.hist + (static_cast<int64_t>(phase) * 3 + pass) * P * kBins;
+}
+
+void robust_fit_region(int n_signals, int phase, int pass, int which, size_t* offset_bytes, size_t* count_u32) {
+  const size_t P = 2 * static_cast<size_t>(n_signals);
+  if (which == 0) {
+    *offset_bytes = sizeof(uint32_t) * (static_cast<size_t>(phase) * 3 + pass) * P * kBins;
+    *count_u32 = P * kBins;
+  } else {
+    *offset_bytes = sizeof(uint32_t) * 2 * 3 * P * kBins + sizeof(FitState) * 2 * P +
+                    sizeof(uint32_t) * static_cast<size_t>(phase) * n_signals;
+    *count_u32 = static_cast<size_t>(n_signals);
+  }
+}
+
+hipError_t launch_fit_begin(void* d_ws, int n_signals, hipStream_t stream) {
+  return hipMemsetAsync(d_ws, 0, robust_fit_workspace_bytes(n_signals), stream);
+}
+
+hipError_t launch_fit_hist(const float* S, int64_t n, int64_t ld, int n_signals, int phase, int pass, const float* med,
+                           void* d_ws, hipStream_t stream) {
+  FitWorkspace w = carve(d_ws, n_signals);
   const int P = 2 * n_signals;
-  uint32_t* hist = w.hist + static_cast<int64_t>(phase) * 3 * P * kBins;
+  uint32_t* hist = hist_of(w, n_signals, phase, pass);
   FitState* state = w.state + phase * P;
   uint32_t* nanc = w.nan_count + phase * n_signals;
   int64_t bx = (n + kFitThreads * 16 - 1) / (kFitThreads * 16);
-  if (bx < 1) bx = 1;
+  if (bx < 1) bx = 1;   // an empty shard still launches (and contributes an all-zero histogram)
   if (bx > 512) bx = 512;
   const dim3 grid(static_cast<unsigned>(bx), static_cast<unsigned>(n_signals));
-  uint32_t* h0 = hist;
-  uint32_t* h1 = hist + static_cast<int64_t>(P) * kBins;
-  uint32_t* h2 = hist + static_cast<int64_t>(2) * P * kBins;
-  hipLaunchKernelGGL((fit_hist_kernel<0, MAD>), grid, dim3(kFitThreads), 0, stream, S, n, ld, med, state, h0, nanc);
-  hipLaunchKernelGGL((fit_pick_kernel<0>), dim3(P), dim3(kFitThreads), 0, stream, h0, state, n);
-  hipLaunchKernelGGL((fit_hist_kernel<1, MAD>), grid, dim3(kFitThreads), 0, stream, S, n, ld, med, state, h1, nanc);
-  hipLaunchKernelGGL((fit_pick_kernel<1>), dim3(P), dim3(kFitThreads), 0, stream, h1, state, n);
-  hipLaunchKernelGGL((fit_hist_kernel<2, MAD>), grid, dim3(kFitThreads), 0, stream, S, n, ld, med, state, h2, nanc);
-  hipLaunchKernelGGL((fit_pick_kernel<2>), dim3(P), dim3(kFitThreads), 0, stream, h2, state, n);
-  hipLaunchKernelGGL(fit_finish_kernel, dim3((n_signals + 63) / 64), dim3(64), 0, stream, state, nanc, n_signals, n, out);
+#define DEWI_HIST(PASS, MAD) \
+  hipLaunchKernelGGL((fit_hist_kernel<PASS, MAD>), grid, dim3(kFitThreads), 0, stream, S, n, ld, med, state, hist, nanc)
+  if (phase == 0) {
+    if (pass == 0) DEWI_HIST(0, false); else if (pass == 1) DEWI_HIST(1, false); else DEWI_HIST(2, false);
+  } else {
+    if (pass == 0) DEWI_HIST(0, true); else if (pass == 1) DEWI_HIST(1, true); else DEWI_HIST(2, true);
+  }
+#undef DEWI_HIST
+  return hipGetLastError();
+}
+
+hipError_t launch_fit_pick(int64_t n_total, int n_signals, int phase, int pass, void* d_ws, hipStream_t stream) {
+  FitWorkspace w = carve(d_ws, n_signals);
+  const int P = 2 * n_signals;
+  const uint32_t* hist = hist_of(w, n_signals, phase, pass);
+  FitState* state = w.state + phase * P;
+  if (pass == 0)
+    hipLaunchKernelGGL((fit_pick_kernel<0>), dim3(P), dim3(kFitThreads), 0, stream, hist, state, n_total);
+  else if (pass == 1)
+    hipLaunchKernelGGL((fit_pick_kernel<1>), dim3(P), dim3(kFitThreads), 0, stream, hist, state, n_total);
+  else
+    hipLaunchKernelGGL((fit_pick_kernel<2>), dim3(P), dim3(kFitThreads), 0, stream, hist, state, n_total);
+  return hipGetLastError();
+}
+
+hipError_t launch_fit_finish(int64_t n_total, int n_signals, int phase, void* d_ws, float* d_out, hipStream_t stream) {
+  FitWorkspace w = carve(d_ws, n_signals);
+  hipLaunchKernelGGL(fit_finish_kernel, dim3((n_signals + 63) / 64), dim3(64), 0, stream, w.state + phase * 2 * n_signals,
+                     w.nan_count + phase * n_signals, n_signals, n_total, d_out);
+  return hipGetLastError();
 }
 
 hipError_t launch_robust_fit(const float* d_S, int64_t n, int64_t ld, int n_signals, float* d_med, float* d_mad,
                              void* d_ws, hipStream_t stream) {
-  FitWorkspace w = carve(d_ws, n_signals);
-  hipError_t e = hipMemsetAsync(d_ws, 0, robust_fit_workspace_bytes(n_signals), stream);
+  hipError_t e = launch_fit_begin(d_ws, n_signals, stream);
   if (e != hipSuccess) return e;
-  run_phase<false>(d_S, n, ld, n_signals, nullptr, w, d_med, stream);
-  run_phase<true>(d_S, n, ld, n_signals, d_med, w, d_mad, stream);
+  for (int phase = 0; phase < 2; ++phase) {
+    for (int pass = 0; pass < 3; ++pass) {
+      if ((e = launch_fit_hist(d_S, n, ld, n_signals, phase, pass, d_med, d_ws, stream)) != hipSuccess) return e;
+      if ((e = launch_fit_pick(n, n_signals, phase, pass, d_ws, stream)) != hipSuccess) return e;
+    }
+    if ((e = launch_fit_finish(n, n_signals, phase, d_ws, phase == 0 ? d_med : d_mad, stream)) != hipSuccess) return e;
+  }
   return hipGetLastError();
 }
 

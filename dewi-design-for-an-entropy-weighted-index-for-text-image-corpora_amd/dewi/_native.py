@@ -36,7 +36,8 @@ EXPORTED_SYMBOLS = (
     "dewi_abi_version", "dewi_last_error", "dewi_device_info", "dewi_normalize_rows_f32",
     "dewi_row_cosine_f32", "dewi_convert_f32_to_bf16", "dewi_payload_soa_f64", "dewi_knn_workspace_bytes", "dewi_knn_rerank_f32",
     "dewi_knn_rerank_bf16", "dewi_knn_rerank_candidates", "dewi_knn_scan", "dewi_knn_finish", "dewi_knn_candidates", "dewi_merge_rerank", "dewi_robust_fit_workspace_bytes",
-    "dewi_robust_fit_f32", "dewi_score_f64", "dewi_timing_enable", "dewi_timing_read", "dewi_tuning_set",
+    "dewi_robust_fit_f32", "dewi_robust_fit_begin", "dewi_robust_fit_hist_f32", "dewi_robust_fit_region",
+    "dewi_robust_fit_pick", "dewi_robust_fit_finish", "dewi_score_f64", "dewi_timing_enable", "dewi_timing_read", "dewi_tuning_set",
 )
 
 
@@ -90,6 +91,16 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.dewi_robust_fit_workspace_bytes.argtypes = [i32]
     lib.dewi_robust_fit_f32.restype = i32
     lib.dewi_robust_fit_f32.argtypes = [vp, i64, i64, i32, vp, vp, vp, sz, vp]
+    lib.dewi_robust_fit_begin.restype = i32
+    lib.dewi_robust_fit_begin.argtypes = [i32, vp, sz, vp]
+    lib.dewi_robust_fit_hist_f32.restype = i32
+    lib.dewi_robust_fit_hist_f32.argtypes = [vp, i64, i64, i32, i32, i32, vp, vp, sz, vp]
+    lib.dewi_robust_fit_region.restype = i32
+    lib.dewi_robust_fit_region.argtypes = [i32, i32, i32, i32, c.POINTER(sz), c.POINTER(sz)]
+    lib.dewi_robust_fit_pick.restype = i32
+    lib.dewi_robust_fit_pick.argtypes = [i64, i32, i32, i32, vp, sz, vp]
+    lib.dewi_robust_fit_finish.restype = i32
+    lib.dewi_robust_fit_finish.argtypes = [i64, i32, i32, vp, sz, vp, vp]
     lib.dewi_score_f64.restype = i32
     lib.dewi_score_f64.argtypes = [vp, i32, i64, i64, c.POINTER(f64), c.POINTER(f64), c.POINTER(f64), f64, i32, vp,
                                    vp, vp]

@@ -65,6 +65,24 @@ class RobustStats:
         """Bulk form of ``fit``: one array per signal instead of one dict per document."""
         return cls(*_fit_columns(columns))
 
+    @classmethod
+    def fit_sharded(cls, local_columns: Mapping[str, np.ndarray], group=None) -> "RobustStats":
+        """``fit_columns`` over the union of every rank's rows (one process per GPU): the exact
+        global median / MAD through ``sharded.ShardedRobustFit``; same result on every rank."""
+        import torch
+        from .sharded import HipFitSteps, ShardedRobustFit
+        nat.load_library()
+        keys = list(local_columns.keys())
+        n_local = len(local_columns[keys[0]])
+        host = np.empty((len(keys), n_local), dtype=np.float32)
+        for j, key in enumerate(keys):
+            host[j] = np.asarray(local_columns[key], dtype=np.float32)      # scorer.py:21 — fp32 cast
+        steps = HipFitSteps(torch.from_numpy(host).cuda())
+        med, mad = ShardedRobustFit(steps, n_local, group=group).fit()
+        medians = {k: float(np.float64(med[j])) for j, k in enumerate(keys)}
+        mads = {k: float(np.float64(mad[j])) or 1e-8 for j, k in enumerate(keys)}   # scorer.py:24
+        return cls(medians, mads)
+
     def z(self, name: str, val: float) -> float:
         return float((val - self.medians[name]) / (1.4826 * self.mads[name]))
 
@@ -83,6 +101,10 @@ class DewiScorer:
 
     def fit_stats_columns(self, columns: Mapping[str, np.ndarray]) -> None:
         self.stats = RobustStats.fit_columns(columns)
+
+    def fit_stats_sharded(self, local_columns: Mapping[str, np.ndarray], group=None) -> None:
+        """Fit on a corpus whose documents are split across ranks (every rank calls this)."""
+        self.stats = RobustStats.fit_sharded(local_columns, group=group)
 
     def is_fitted(self) -> bool:
         return self.stats is not None

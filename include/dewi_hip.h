@@ -176,6 +176,27 @@ int dewi_robust_fit_f32(const float* d_S, int64_t n, int64_t ld, int n_signals, 
                         void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * A6 over doc-id shards ("fit_stats shards too").  The same exact select, split at
+ * its histogram boundaries so that the rows of a column may live on several GPUs:
+ *   begin                                   zero the workspace
+ *   for phase in (0 median, 1 MAD):         (phase 1 needs d_med = the medians phase 0 produced)
+ *     for pass in (0, 1, 2):                11 + 11 + 10 key bits
+ *       hist(local rows)  ->  caller SUMS the u32 regions `which` = 0 (histograms, every pass) and
+ *       `which` = 1 (NaN counts, pass 0 only) over ranks (RCCL all-reduce)  ->  pick(n_total)
+ *     finish(n_total) -> d_out[n_signals]   identical on every rank
+ * With one rank and no reduction the sequence IS dewi_robust_fit_f32.  n_local may be 0.
+ * dewi_robust_fit_region reports where a region lies inside the workspace (byte offset, u32 count).
+ * ------------------------------------------------------------------------------------------ */
+int dewi_robust_fit_begin(int n_signals, void* d_workspace, size_t workspace_bytes, void* stream);
+int dewi_robust_fit_hist_f32(const float* d_S, int64_t n_local, int64_t ld, int n_signals, int phase, int pass,
+                             const float* d_med, void* d_workspace, size_t workspace_bytes, void* stream);
+int dewi_robust_fit_region(int n_signals, int phase, int pass, int which, size_t* offset_bytes, size_t* count_u32);
+int dewi_robust_fit_pick(int64_t n_total, int n_signals, int phase, int pass, void* d_workspace,
+                         size_t workspace_bytes, void* stream);
+int dewi_robust_fit_finish(int64_t n_total, int n_signals, int phase, void* d_workspace, size_t workspace_bytes,
+                           float* d_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * A7+A8  DEWI score — replaces RobustStats.z, DewiScorer._components, score, score_conditional
  * (scorer.py:28-31, 49-89), float64 arithmetic in the reference's operation order:
  *   z = (x - med) / (1.4826 * mad);  Ht = .5(z0+z1)  Hi = .5(z2+z3)  I = z4  R = z5  N = z6

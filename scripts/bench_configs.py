@@ -71,6 +71,10 @@ ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
 t = timed(lambda: nat.check(lib.dewi_robust_fit_f32(nat.ptr(sig), n, n, 7, nat.ptr(med), nat.ptr(mad), nat.ptr(ws), wsb,
                                                     nat.stream_ptr())))
 out["C5_robust_fit_7x1M"] = {"ms": round(t * 1e3, 4), "algorithmic_GBps": round(2 * 3 * 7 * n * 4 / t / 1e9, 1)}
+from dewi.sharded import HipFitSteps, ShardedRobustFit  # noqa: E402
+fit1 = ShardedRobustFit(HipFitSteps(sig), n)      # world 1: the split entry points, 21 C-ABI calls + 2 D2H
+t = timed(lambda: fit1.fit())
+out["C5_robust_fit_7x1M_split_steps"] = {"ms": round(t * 1e3, 4)}
 import ctypes
 arr7 = ctypes.c_double * 7
 m7 = arr7(*med.cpu().double().tolist())

@@ -25,7 +25,9 @@ def _corpus(n, dim, seed):
 
 
 @pytest.mark.parametrize("dim,n,b,k", [(768, 70_001, 256, 100), (768, 66_000, 40, 10), (512, 80_000, 300, 10),
-                                       (256, 70_000, 17, 100), (128, 131_072, 64, 10)])
+                                       (256, 70_000, 17, 100), (128, 131_072, 64, 10),
+                                       (128, 1_100_000, 32, 10)])   # > 32 K sample scores per query: thresholds
+                                                                    # from global memory instead of LDS
 def test_mfma_batched_vs_oracle(dim, n, b, k):
     cb, Eb, dewi32, ent32 = _corpus(n, dim, seed=dim + b)
     Q = orc.synth_queries(b, dim, seed=b)
