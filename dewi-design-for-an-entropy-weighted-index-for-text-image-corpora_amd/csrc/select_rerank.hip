@@ -47,18 +47,43 @@ __device__ void rerank_and_emit(SelectShared& sh, int n_sel, int k, const Rerank
   if (n_sel <= kRankSortMax) {
     // few candidates: each thread ranks its own adjusted key and writes its output slot directly
     __syncthreads();
-    for (int t = tid; t < n_sel; t += nt) {
-      const uint64_t mine = sh.sel2[t];
-      int rank = 0;
-      for (int j = 0; j < n_sel; ++j) rank += sh.sel2[j] > mine ? 1 : 0;  // adjusted keys are unique (low word = t)
-      if (rank < k) {
-        int64_t id = my_id;
-        if (t != tid) {  // more candidates than threads: fetch again
-          float dewi, ent;
-          fetch(t, dewi, ent, id);
+    const int S = rank_split(n_sel, nt);
+    if (S == 1) {
+      for (int t = tid; t < n_sel; t += nt) {
+        const uint64_t mine = sh.sel2[t];
+        int rank = 0;
+#pragma unroll 4
+        for (int j = 0; j < n_sel; ++j) rank += sh.sel2[j] > mine ? 1 : 0;  // adjusted keys are unique (low word = t)
+        if (rank < k) {
+          int64_t id = my_id;
+          if (t != tid) {  // more candidates than threads: fetch again
+            float dewi, ent;
+            fetch(t, dewi, ent, id);
+          }
+          out_ids[rank] = id;
+          out_scores[rank] = unord_f32(static_cast<uint32_t>(mine >> 32));
         }
-        out_ids[rank] = id;
-        out_scores[rank] = unord_f32(static_cast<uint32_t>(mine >> 32));
+      }
+    } else {
+      // S lanes share a candidate: each counts a slice of the comparisons (see rank_sort_desc)
+      const int part = tid & (S - 1);
+      for (int t = tid / S; t < n_sel; t += nt / S) {
+        const uint64_t mine = sh.sel2[t];
+        int rank = 0;
+        const int iters = (n_sel + S - 1) / S;   // uniform trip count, see rank_sort_desc
+#pragma unroll 8
+        for (int i = 0; i < iters; ++i) {
+          const int j = part + i * S;
+          rank += sh.sel2[j < p2 ? j : p2 - 1] > mine ? 1 : 0;   // sel2[n_sel .. p2) holds empty keys (never greater)
+        }
+        for (int m = 1; m < S; m <<= 1) rank += __shfl_xor(rank, m, kWave);
+        if (part == 0 && rank < k) {
+          float dewi, ent;
+          int64_t id;
+          fetch(t, dewi, ent, id);
+          out_ids[rank] = id;
+          out_scores[rank] = unord_f32(static_cast<uint32_t>(mine >> 32));
+        }
       }
     }
     return;
@@ -103,6 +128,34 @@ __device__ int exact_top_candidates(const Keys& keys, int n_candidates, SelectSh
     rank_sort_desc(sh.sel2, sh.sel, n_sel);
     return n_sel;
   }
+  bitonic_sort_desc<false>(sh.sel, nullptr, p2);
+  return n_sel;
+}
+
+// Same for a dense LDS array of unique keys (survivors of the batched matrix-core scan), using the
+// prefix-skipping 11-bit select.
+__device__ int top_candidates_lds(const uint64_t* keys, int n, int n_candidates, SelectShared& sh, WideRadixShared& ws) {
+  const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
+  const uint64_t thr = block_kth_largest_lds(keys, n, static_cast<uint32_t>(n_candidates), ws);
+  if (tid == 0) sh.count = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += nt) {
+    const uint64_t key = keys[i];
+    if (key >= thr) {
+      const uint32_t pos = atomicAdd(&sh.count, 1u);   // exactly min(n, n_candidates) keys pass
+      sh.sel2[pos] = key;
+    }
+  }
+  __syncthreads();
+  const int n_sel = static_cast<int>(sh.count);
+  if (n_sel <= kRankSortMax) {
+    if (tid < kWave) sh.sel2[n_sel + tid] = kKeyEmpty;   // padding for the unmasked ranking loop
+    __syncthreads();
+    rank_sort_desc<true>(sh.sel2, sh.sel, n_sel);
+    return n_sel;
+  }
+  const int p2 = pow2_at_least(n_sel);
+  for (int t = tid; t < p2; t += nt) sh.sel[t] = t < n_sel ? sh.sel2[t] : kKeyEmpty;
   bitonic_sort_desc<false>(sh.sel, nullptr, p2);
   return n_sel;
 }
@@ -277,39 +330,105 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(
     // re-runs it on the exact small-batch path (ids = -1 is the documented marker).
     SegmentKeys kv{keys_all + static_cast<int64_t>(q) * seg.cap, counts + q, seg.seg_stride, seg.count_stride, seg.n_seg,
                    seg.cap, seg.raw != 0};
-    if (tid == 0) sh.total = 0;
-    __syncthreads();
-    for (int s = tid; s < seg.n_seg; s += nt)
-      if (kv.count[s * kv.count_stride] > static_cast<uint32_t>(seg.cap)) sh.total = 1;
-    __syncthreads();
-    if (sh.total) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t dyn_keys[];
+    __shared__ WideRadixShared ws;
+    __shared__ uint32_t seg_base[kSelectThreads], seg_cnt[kSelectThreads];
+    const uint32_t cap = static_cast<uint32_t>(seg.cap);
+    auto refuse = [&]() {
       for (int j = tid; j < k; j += nt) {
         out_ids[static_cast<int64_t>(q) * k + j] = -1;
         out_scores[static_cast<int64_t>(q) * k + j] = __builtin_nanf("");
       }
-      return;
+    };
+    if (tid == 0) sh.total = 0;
+    __syncthreads();
+    if (seg.n_seg <= nt && seg.raw != 0) {
+      // One thread per half-segment: its count gives the overflow verdict and, through a workgroup
+      // prefix sum, the place of its records in the dense LDS array — no position atomics, and the
+      // counts are read once.
+      const int lane = tid & 63, wave = tid >> 6, n_waves = nt >> 6;
+      uint32_t c = 0;
+      if (tid < seg.n_seg) {
+        c = kv.count[tid * kv.count_stride];
+        if (c > cap) sh.total = 1;
+        c = c < cap ? c : cap;
+      }
+      uint32_t incl = c;
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, kWave);
+        if (lane >= off) incl += o;
+      }
+      if (lane == 63) ws.wave_tot[wave] = incl;
+      __syncthreads();
+      if (sh.total) {
+        refuse();
+        return;
+      }
+      uint32_t before = 0, total = 0;
+      for (int w = 0; w < n_waves; ++w) {
+        const uint32_t wt = ws.wave_tot[w];
+        before += w < wave ? wt : 0u;
+        total += wt;
+      }
+      seg_base[tid] = before + incl - c;
+      seg_cnt[tid] = c;
+      __syncthreads();
+      if (total <= static_cast<uint32_t>(seg.lds_keys)) {
+        // Two lanes per half-segment, 8 predicated loads each issued back to back (a per-lane trip
+        // count would make hipcc wait after every load); segments with more than 16 records loop.
+        constexpr int kGroup = 2, kBatch = 8;
+        const int sub = tid % kGroup;
+        for (int sg = tid / kGroup; sg < seg.n_seg; sg += nt / kGroup) {
+          const uint32_t n_rec = seg_cnt[sg], b = seg_base[sg];
+          const uint64_t* sp = kv.p + sg * kv.seg_stride;
+          for (uint32_t j0 = 0; j0 < n_rec; j0 += kGroup * kBatch) {
+            uint64_t v[kBatch];
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+              const uint32_t j = j0 + sub + u * kGroup;
+              v[u] = j < n_rec ? sp[j] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+              const uint32_t j = j0 + sub + u * kGroup;
+              if (j < n_rec)
+                dyn_keys[b + j] = make_key(__uint_as_float(static_cast<uint32_t>(v[u])), static_cast<uint32_t>(v[u] >> 32));
+            }
+          }
+        }
+        __syncthreads();
+        n_sel = top_candidates_lds(dyn_keys, static_cast<int>(total), n_candidates, sh, ws);
+      } else {
+        n_sel = exact_top_candidates(kv, n_candidates, sh);   // more survivors than LDS holds
+      }
+    } else {
+      for (int s = tid; s < seg.n_seg; s += nt)
+        if (kv.count[s * kv.count_stride] > cap) sh.total = 1;
+      __syncthreads();
+      if (sh.total) {
+        refuse();
+        return;
+      }
+      __syncthreads();
+      // Gather the valid records of the half-segments into LDS once; the radix-select passes then run
+      // over a dense LDS array instead of re-walking global memory five times.
+      if (tid == 0) sh.count = 0;
+      __syncthreads();
+      kv.for_each(tid, nt, [&](uint64_t key) {
+        const uint32_t pos = atomicAdd(&sh.count, 1u);
+        if (pos < static_cast<uint32_t>(seg.lds_keys)) dyn_keys[pos] = key;
+      });
+      __syncthreads();
+      const uint32_t total = sh.count;
+      __syncthreads();
+      if (total <= static_cast<uint32_t>(seg.lds_keys))
+        n_sel = exact_top_candidates(ArrayKeys{dyn_keys, static_cast<int64_t>(total)}, n_candidates, sh);
+      else
+        n_sel = exact_top_candidates(kv, n_candidates, sh);
     }
-    __syncthreads();
-    // Gather the valid records of the hundreds of half-segments into LDS once; the radix-select
-    // passes then run over a dense LDS array instead of re-walking global memory five times.
-    extern __shared__ __attribute__((aligned(16))) uint64_t dyn_keys[];
-    if (tid == 0) sh.count = 0;
-    __syncthreads();
-    kv.for_each(tid, nt, [&](uint64_t key) {
-      const uint32_t pos = atomicAdd(&sh.count, 1u);
-      if (pos < static_cast<uint32_t>(seg.lds_keys)) dyn_keys[pos] = key;
-    });
-    __syncthreads();
-    const uint32_t total = sh.count;
-    __syncthreads();
-    if (total <= static_cast<uint32_t>(seg.lds_keys))
-      n_sel = exact_top_candidates(ArrayKeys{dyn_keys, static_cast<int64_t>(total)}, n_candidates, sh);
-    else
-      n_sel = exact_top_candidates(kv, n_candidates, sh);
   } else {
     n_sel = gather_top_candidates(keys, keys_per_query, sorted_lists, n_candidates, sh);
   }
-
   if (out_cand != nullptr) {
     dewi_candidate* oc = out_cand + static_cast<int64_t>(q) * n_candidates;
     for (int t = tid; t < n_candidates; t += nt) {
