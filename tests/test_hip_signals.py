@@ -10,7 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n,d", [(1000, 512), (257, 10), (64, 768), (5, 3)])
+@pytest.mark.parametrize("n,d", [(1000, 512), (4097, 512), (3, 512), (257, 10), (64, 768), (5, 3)])
 def test_cross_modal_similarity_matches_torch(n, d):
     import torch
     import torch.nn.functional as F
