@@ -6,14 +6,21 @@
 // S = Qb * Eb^T is computed tile by tile with v_mfma_f32_32x32x16_bf16 and never written; an
 // epilogue keeps only scores that can still reach the top c.
 //
-// Roofline: co-limited.  Algorithmic bytes per pass = n_rows*dim*2 (HBM, read once); flops =
-// 2*256*n_rows*dim (393 GFLOP at C3) -> 256 flop/B against a ~310 flop/B machine balance.
-// What actually bounds this kernel is LDS bandwidth: with the queries resident in registers every
-// MFMA (32 matrix-pipe cycles) consumes one 1 KiB A fragment from LDS, and four SIMDs doing that
-// back to back ask for exactly the LDS peak (128 B/clk/CU).  Measured at C3: 344 us per pass; with
-// the MFMAs removed (LDS reads, DMA and epilogue only) 323 us; with the epilogue removed 302 us.
-// Two 32-query blocks per A fragment would halve the LDS traffic but need 384 query registers per
-// wave at dim 768 (4 waves x 512 registers: no second wave to cover the epilogue — measured 492 us).
+// Roofline: co-limited on paper.  Algorithmic bytes per pass = n_rows*dim*2 (HBM, read once);
+// flops = 2*256*n_rows*dim (393 GFLOP at C3) -> 256 flop/B against a ~310 flop/B machine balance.
+// Measured at C3: ~350 us per pass = 4.4 TB/s and 1.12 PFLOP/s (45 % of the 2.5 PF peak quoted at
+// 2.4 GHz; the kernel clocks ~1.7 GHz, at which the matrix pipe is busy 3.07 K of every 4.6 K
+// cycles = 67 %).  What bounds it is neither HBM nor LDS bandwidth (ds_read_b128 peaks at 256 B/clk
+// per CU; the A fragments ask for 128) but the two waves of a SIMD sharing one matrix pipe and one
+// vector-issue port: per 32-document tile a SIMD owes 96 MFMAs = 3072 pipe cycles, and whatever
+// the other wave does meanwhile (12 DMA pieces at ~60 issue cycles, the filter's compares/selects,
+// 1-2 survivor stores at ~90) comes out of the same SIMD — re-placing that work between the waves
+// is zero-sum (MI355X_MICROARCH.md, "Two waves per SIMD").  In-kernel stamps, cycles per tile and
+// wave: matrix block 1.6-1.8 K (48 MFMAs x 32 = 1536 ideal), side phase 1.7-1.9 K (DMA issue 0.35-
+// 0.45 K, wait for own pieces 0.15 K, filter ~1.1 K), barrier 0.7-1.1 K.  Ablations: no DMA after
+// the first tile 292 us, no filter 305 us.  Two 32-query blocks per A fragment (half the LDS reads,
+// half the waves) need 384 query registers per wave at dim 768: 4 waves x 512 registers measured
+// 492 us (no partner wave to cover the side phase).
 //
 // Structure (one 8-wave workgroup per CU, two waves per SIMD, persistent over 32-document tiles):
 //  * QUERIES LIVE IN REGISTERS.  Wave w owns queries 32w..32w+31 for the whole kernel: their B
@@ -21,24 +28,34 @@
 //    traffic, no LDS for Q.
 //  * DOCUMENT TILES GO THROUGH LDS BY DMA.  A tile (32 rows x dim bf16 = 48 KiB) is copied
 //    global->LDS with buffer_load_dwordx4 ... lds (1 KiB per wave-instruction, no VGPR staging)
-//    into a ring of three slots: tiles i+1 and i+2 are in flight while tile i is multiplied
-//    (counted vmcnt, one raw s_barrier per tile).  With two slots a tile had one matrix block
-//    (~3 K cycles) to arrive, about one loaded HBM latency: 96 KiB in flight per CU fixes that.  All 8 waves read the same tile (A operand) with ds_read_b128.
+//    into a ring of three slots: tiles i+1 and i+2 are in flight while tile i is multiplied.  All 8
+//    waves read the same tile (A operand) with ds_read_b128, three fragments ahead of the MFMA.
 //  * BANK CONFLICTS: rows are 1536 B apart (= 0 mod 256 B), so an A-fragment read (16 lanes = 16
 //    rows, same 16-byte column unit) would be 16-way conflicted.  The LDS image is linear (DMA
 //    writes base + lane*16) and the SOURCE address is permuted instead: unit c of row r is stored
-//    at unit (c & ~15) | ((c & 15) ^ (r & 15)); reads apply the same XOR -> conflict-free.
-//  * EPILOGUE.  D[doc][query]: lane l holds query l&31 (+32) and 16 documents.  Filter mode: a
-//    score passes if it is not below the query's threshold (a lower bound of its final c-th best
-//    score, from a strided 1/32 sample of the corpus scanned in dense mode first).  Survivors
-//    (~32c per query over the whole pass) go to a half-segment PRIVATE to one lane: a query
-//    belongs to one wave and to two of its lanes, so the slot counter is a register and the record
-//    a fire-and-forget global store — no atomics, nothing that drains the DMA queue.  (Appending
-//    with returning global atomics: 1.85 ms per pass; LDS counters + per-element predication:
-//    0.54 ms, 1/3 of it epilogue.)  One v_cmp + execz branch per accumulator register: registers
-//    without survivors (most of them) cost a compare and a scalar branch.  If a half-segment
-//    overflows (only for adversarial corpora, e.g. tens of thousands of exact duplicates of a top
-//    document) its count keeps growing and the finish kernel flags the query.
+//    at unit (c & ~15) | ((c & 15) ^ (r & 15)); reads apply the same XOR -> conflict-free (also for
+//    the 4 x 16-lane groups ds_read_b128 really uses: {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...).
+//  * A PERIOD HAS TWO HALVES PER WAVE: the matrix block (48 x [counted wait, MFMA, read 3 ahead],
+//    s_setprio 3, nothing else — a DMA instruction between the MFMAs stalled the in-order wave for
+//    60-180 cycles each and the block ran at 45-60 cycles per k-step) and the side phase (wait for
+//    own pieces of the next tile: vmcnt(0), everything outstanding is a period old; send the pieces
+//    of tile i+2; filter a finished tile).  Waves 0-3 run block(i) then side(i); waves 4-7 run
+//    side(i-1) then block(i): the two waves of a SIMD are always in opposite halves.  One s_barrier
+//    per tile.
+//  * FILTER.  D[doc][query]: lane l holds query l&31 (+32) and 16 documents.  A score passes if it is
+//    not below the query's threshold (a lower bound of its final c-th best score, from a strided
+//    1/32 sample of the corpus scanned in dense mode first).  Survivors (~32c per query over the
+//    whole pass) go to a half-segment PRIVATE to one lane: a query belongs to one wave and to two
+//    of its lanes, so the write position is a register and the record a fire-and-forget global
+//    store — no atomics.  Stores and taken branches are what costs here, not compares, so a lane
+//    compacts first (branch-free select chain: first passing score + pass mask) and the wave
+//    issues ONE predicated store; lanes with a second survivor in the same tile (one tile in
+//    four has one) go round again.  History of the filter per pass: returning global atomics
+//    1.85 ms; LDS counters + per-element predication 0.54 ms; execz branch + store per register
+//    1.8 K cycles per tile and wave; 16 predicated stores without branches 1.45 K; compaction
+//    ~1.1 K.  If a half-segment overflows (only for adversarial corpora, e.g. tens of thousands of
+//    exact duplicates of a top document) its count keeps growing and the finish kernel flags the
+//    query.
 #include "select_common.hpp"
 
 namespace dewi {
@@ -59,6 +76,12 @@ constexpr int kQueriesPerPass = 256;  // 8 waves x 32 (or 4 x 64)
 constexpr int kSampleStride = 32;     // every 32nd tile is a sample tile
 constexpr int kMaxStagedSample = 32 * 1024;  // sample scores per query the threshold kernel keeps in LDS (128 KiB)
 constexpr int kTileBufs = 3;          // LDS ring: the tile being multiplied + two tiles of DMA in flight
+#ifndef DEWI_MFMA_AHEAD
+#define DEWI_MFMA_AHEAD 3   // A fragments in flight ahead of the MFMA being fed (4 VGPRs each; 2..10 measured equal)
+#endif
+#ifndef DEWI_MFMA_PRIO
+#define DEWI_MFMA_PRIO 1
+#endif
 #ifndef DEWI_MFMA_ABLATE
 #define DEWI_MFMA_ABLATE 0   // timing experiments only: 1 no epilogue, 2 no DMA after the first tile, 3 no MFMA
 #endif
@@ -141,10 +164,14 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
 #pragma unroll
   for (int b = 0; b < kQB; ++b) asm volatile("" ::"v"(thr_l[b]));
 
-  // ---- per-lane DMA source offsets (bytes from the tile's first row), one per piece this wave moves
-  uint32_t voff[PPW];
+  // ---- per-lane DMA source offsets (bytes from the tile's first row).  The swizzle repeats every
+  // 16 rows (= KS/2 pieces), so where that is a whole number of this wave's pieces (KS % 16 == 0)
+  // piece i and piece i + VO differ by the constant 16 * DIM * 2 bytes, which goes into the
+  // instruction's scalar offset: VO = KS/16 registers instead of PPW = KS/8.
+  constexpr int VO = (KS % 16 == 0) ? KS / 16 : PPW;
+  uint32_t voff[VO];
 #pragma unroll
-  for (int i = 0; i < PPW; ++i) {
+  for (int i = 0; i < VO; ++i) {
     const int piece = i * NW + wave;
     const int x = piece * 64 + lane;               // LDS unit this lane fills
     const int row = x / UPR, cp = x % UPR;
@@ -152,6 +179,9 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
     voff[i] = static_cast<uint32_t>(row * (DIM * 2) + c * 16);
   }
   // ---- per-lane A-fragment read offsets inside a tile buffer
+  // unit (2j) ^ z of row r, j = k-step mod 8: eight address registers (a v_xor per read instead would
+  // save seven of them but costs a vector-issue slot per k-step, and issue slots are what this kernel
+  // runs out of: see the roofline note at the top).
   const int z = (r & 15) ^ h;
   uint32_t a_addr[8];  // LDS byte addresses for ring slot 0; advanced to the next slot in place every tile
 #pragma unroll
@@ -174,20 +204,20 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
   };
   auto issue_piece = [&](__amdgpu_buffer_rsrc_t rsrc, int buf, int i) {
     char* l = lds + buf * TILE_BYTES + (i * NW + wave_u) * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)(l), 16, voff[i], 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)(l), 16, voff[i % VO], (i / VO) * (16 * DIM * 2), 0, 0);
   };
 
   // ---- survivor segments.  Queries belong to exactly one wave and to exactly two of its lanes
   // (l and l+32, which hold different documents), so each LANE owns a private half-segment per
   // query block and its slot counter is a plain register: no atomics of any kind.
   // segment index = 2*blockIdx.x + h; keys at out[(segment*256 + q) * out_stride + slot].
-  // slot[b] = index into `out` of the next free record of this lane's half-segment (32-bit: the
-  // whole candidate area is far below 2^32 records).
-  uint32_t slot[kQB];
+  // off[b] = BYTE offset into `out` of the next free record of this lane's half-segment (32-bit: the
+  // whole candidate area is far below 4 GiB); the stores address `out` as SGPR base + VGPR offset.
+  uint32_t off[kQB];
 #pragma unroll
   for (int b = 0; b < kQB; ++b)
-    slot[b] = ((static_cast<uint32_t>(blockIdx.x) * 2 + h) * kQueriesPerPass + (32 * kQB * wave + 32 * b + r)) *
-              static_cast<uint32_t>(out_stride);
+    off[b] = ((static_cast<uint32_t>(blockIdx.x) * 2 + h) * kQueriesPerPass + (32 * kQB * wave + 32 * b + r)) *
+             static_cast<uint32_t>(out_stride) * 8u;
 
   const int64_t first = static_cast<int64_t>(blockIdx.x);
   const int64_t step = static_cast<int64_t>(gridDim.x);
@@ -225,20 +255,79 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
 #pragma unroll
         for (int j = 0; j < 16; ++j) dense[(j & 3) + 8 * (j >> 2)] = acc[b][j];
       } else {
+        // Filtering a lane's 16 scores.  What this costs is NOT the compares: vector ALU work of the
+        // filtering wave issues in the gaps of the partner wave's MFMAs (an MFMA holds the SIMD's vector
+        // issue for 8 of its 32 cycles).  It is the global stores — ~90 cycles of issue each, with however
+        // few lanes enabled (measured: one predicated store per accumulator register, 16 per tile and
+        // wave, 1.45 K cycles; an execz branch around each store, ~5 taken per tile, 1.8 K) — and taken
+        // branches.  So a lane first COMPACTS: a branch-free select chain keeps its first passing score
+        // (and that score's row) and counts the passing ones; one predicated store then serves every
+        // lane of the wave.  A lane rarely has a second survivor in the same tile (~0.5 %, i.e. one tile
+        // in four has such a lane somewhere in the wave); those go round again: chain over the registers
+        // behind the one already stored, one more store.
+        // The per-store capacity check is hoisted: one ballot per tile decides whether every lane has room
+        // for 16 more records; only an (adversarial) nearly full half-segment takes the checked path below.
+        const uint32_t seg_q = (static_cast<uint32_t>(blockIdx.x) * 2 + h) * kQueriesPerPass + (32 * kQB * wave + 32 * b + r);
+        const uint32_t end_bytes = (seg_q + 1u) * static_cast<uint32_t>(out_stride) * 8u;
+        const bool tight = off[b] + 16u * 8u > end_bytes;   // also true once the segment has overflowed
+        if (__builtin_amdgcn_ballot_w64(tight) == 0ull && DEWI_MFMA_ABLATE != 4) {
+          // raw record: high word = document row, low word = fp32 score bits (the finish kernel builds the
+          // ordered key).  NaN passes (NumPy ranks NaN first): the test is "not below".
+          auto store_where = [&](uint32_t flag, uint32_t row_off, float score) {
+            const uint64_t rec = (static_cast<uint64_t>(static_cast<uint32_t>(doc0) | row_off) << 32) | __float_as_uint(score);
+            uint64_t saved_exec;
+            asm volatile(
+                "v_cmp_ne_u32 vcc, 0, %[f]\n\t"
+                "s_and_saveexec_b64 %[sv], vcc\n\t"
+                "global_store_dwordx2 %[off], %[rec], %[base]\n\t"
+                "v_add_u32 %[off], 8, %[off]\n\t"
+                "s_mov_b64 exec, %[sv]"
+                : [off] "+v"(off[b]), [sv] "=&s"(saved_exec)
+                : [f] "v"(flag), [rec] "v"(rec), [base] "s"(out)
+                : "vcc", "memory");
+          };
+          // Three vector instructions per register: the compare, a select for the score, and an
+          // add-with-carry that shifts the lane's pass bit into a mask (mask = 2 mask + pass), from which
+          // the count (popcount) and the first passing register (lowest set bit) follow at the end.
+          uint32_t mask = 0;
+          float first = 0.f;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          // one v_cmp + s_and_saveexec + s_cbranch_execz per accumulator register: registers in
-          // which no lane passes (most of them) fall straight through
-          const bool pass = !(acc[b][j] < thr_l[b]);           // NaN passes (NumPy ranks NaN first)
-          if (pass) {
-            const uint32_t seg_q = (static_cast<uint32_t>(blockIdx.x) * 2 + h) * kQueriesPerPass + (32 * kQB * wave + 32 * b + r);
-            if (slot[b] - seg_q * static_cast<uint32_t>(out_stride) < static_cast<uint32_t>(out_stride)) {
-              // raw record: high word = document row, low word = fp32 score bits (the finish kernel
-              // builds the ordered key)
-              out[slot[b]] = (static_cast<uint64_t>(static_cast<uint32_t>(doc0 + (j & 3) + 8 * (j >> 2))) << 32) |
-                             __float_as_uint(acc[b][j]);
+          for (int j = 15; j >= 0; --j) {   // descending, so the LOWEST passing register is the one kept
+            const bool pass = !(acc[b][j] < thr_l[b]);
+            first = pass ? acc[b][j] : first;
+            mask = mask + mask + (pass ? 1u : 0u);    // bit (15 - j') of the final mask ... register j ends at bit j
+          }
+          uint32_t n_pass = static_cast<uint32_t>(__builtin_popcount(mask));
+          const uint32_t j0 = static_cast<uint32_t>(__builtin_ctz(mask | 0x10000u));   // first passing register (16: none)
+          uint32_t ro = (j0 & 3u) + 8u * (j0 >> 2);
+          store_where(n_pass, ro, first);
+          uint32_t more = n_pass > 1u ? 1u : 0u;
+          while (__builtin_amdgcn_ballot_w64(more != 0u) != 0ull) {
+            uint32_t ro_next = 0;
+            float next = 0.f;
+#pragma unroll
+            for (int j = 15; j >= 1; --j) {   // row offsets grow with j: "behind the stored one" = larger offset
+              const uint32_t roj = static_cast<uint32_t>((j & 3) + 8 * (j >> 2));
+              const bool pass = !(acc[b][j] < thr_l[b]) && roj > ro;
+              next = pass ? acc[b][j] : next;
+              ro_next = pass ? roj : ro_next;
             }
-            ++slot[b];
+            store_where(more, ro_next, next);
+            ro = more ? ro_next : ro;
+            n_pass -= more;
+            more = n_pass > 1u ? 1u : 0u;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const bool pass = !(acc[b][j] < thr_l[b]);
+            if (pass) {
+              if (off[b] < end_bytes && DEWI_MFMA_ABLATE != 4) {
+                out[off[b] >> 3] = (static_cast<uint64_t>(static_cast<uint32_t>(doc0 + (j & 3) + 8 * (j >> 2))) << 32) |
+                                   __float_as_uint(acc[b][j]);
+              }
+              off[b] += 8u;   // keeps counting past the end: the finish kernel sees count > capacity
+            }
           }
         }
       }
@@ -249,80 +338,137 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
   // SIMD is therefore in its matrix block while the other is in its (matrix-pipe-idle) epilogue,
   // instead of both competing for the pipe and then both leaving it idle.
   const bool deferred = wave_u >= NW / 2;
+#ifdef DEWI_MFMA_STAMPS
+  uint64_t st_dma = 0, st_vm = 0, st_wait = 0, st_mfma = 0, st_epi = 0, st_t0 = __builtin_readcyclecounter(), st_tiles = 0;
+#define ST_NOW() __builtin_readcyclecounter()
+#endif
   f32x16 acc[kQB];
   int64_t prev = -1;
   int buf = 0;
+  // first tile: its pieces are the older half of the prologue's DMA
+  if (first + step < n_tiles && DEWI_MFMA_ABLATE != 2) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   for (int64_t i = first; i < n_tiles; i += step) {
-    const int64_t tile = i * tile_stride;
     // tile i+2 is fetched while tile i is multiplied: a tile has two whole iterations to land
     const bool has_next2 = (i + 2 * step < n_tiles) && DEWI_MFMA_ABLATE != 2;
-    const bool has_next1 = (i + step < n_tiles) && DEWI_MFMA_ABLATE != 2;
-    // Outstanding, oldest first: this tile's pieces, the next tile's pieces (issued during the previous
-    // matrix block), then the previous epilogue's few survivor stores.  Leaving the PPW youngest
-    // operations in flight therefore guarantees this tile has landed (it over-waits by one piece per
-    // survivor store, which is harmless).
-    if (has_next1) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();   // (a) every wave's pieces of this tile have landed
-                                    // (b) every wave has finished reading the slot of tile i-1, which
-                                    //     the DMA of tile i+2 (issued below) refills
+#ifdef DEWI_MFMA_STAMPS
+    const uint64_t st_a = ST_NOW();
+#endif
+    // One barrier per tile: (a) every wave's pieces of this tile have landed (each waited for its own in
+    // its side phase), (b) every wave has finished reading the slot of tile i-1, which the DMA of tile i+2
+    // refills.  Every wave idles ~0.7-1.1 K cycles of a 4.6 K-cycle period here, but the barrier is also
+    // what keeps the two waves of a SIMD in complementary phases: per-wave progress flags in LDS (block
+    // on "tile landed", DMA on "slot free", a tile of slack) ran 383 us against 355.
+    __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const int buf2 = buf + 2 >= kTileBufs ? buf + 2 - kTileBufs : buf + 2;
-    const __amdgpu_buffer_rsrc_t next_rsrc = tile_rsrc(has_next2 ? (i + 2 * step) * tile_stride : tile);
 
-    if (deferred && prev >= 0) epilogue(acc, prev);
+    // A fragments are read kAhead k-steps ahead of the MFMA that consumes them.  hipcc sinks plain LDS
+    // loads back next to their use at this register pressure, so the reads and their counted waits are
+    // inline asm: LDS returns data in order, hence before step s may start at most the kAhead younger
+    // reads may be pending.  The wait statement takes the fragment as an in/out operand so that the
+    // MFMA cannot be scheduled above it.  No other LGKM operation is issued between the first read and
+    // the last wait.  The first kAhead reads go out right behind the barrier — for the deferred waves
+    // that is BEFORE their epilogue, so their matrix block starts on fragments that are already there.
+    constexpr int kAhead = DEWI_MFMA_AHEAD < KS - 1 ? DEWI_MFMA_AHEAD : KS - 1;
+    u32x4m ring[kAhead + 1];
+    auto read_fragment = [&](u32x4m& dst, int s) {
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(a_addr[s & 7]), "n"(256 * (s >> 3)));
+    };
 #pragma unroll
-    for (int b = 0; b < kQB; ++b) {
+    for (int s = 0; s < kAhead; ++s) read_fragment(ring[s], s);
+
+    // The half of a period a wave does NOT spend in its matrix block: wait for its pieces of the next
+    // tile, send the pieces of tile i+2, filter a finished tile.  The DMA is issued here and not between
+    // the MFMAs: a vector-memory instruction that queues up stalls the in-order wave behind it, which
+    // showed as gaps in the matrix pipe (~45-60 cycles per k-step instead of 32).
+    //   vmcnt(0): the only vector-memory operations outstanding are this wave's pieces of tile i+1 and
+    //   the survivor stores of its previous epilogue, all a whole period old — no stall, and no
+    //   dependence on how many stores there were.  Tile i+2 goes into the ring slot of tile i-1, which
+    //   every wave finished reading before the barrier above.
+    auto side_phase = [&](bool filter, int64_t filter_tile) {
+#ifdef DEWI_MFMA_STAMPS
+      const uint64_t sp0 = ST_NOW();
+#endif
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef DEWI_MFMA_STAMPS
+      const uint64_t sp1 = ST_NOW();
+#endif
+      if (has_next2) {
+        const __amdgpu_buffer_rsrc_t next_rsrc = tile_rsrc((i + 2 * step) * tile_stride);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) acc[b][j] = 0.f;
-    }
-    // A fragments are read two k-steps ahead of the MFMAs that consume them (each feeds two MFMAs,
-    // 64 cycles of matrix work per read).  hipcc sinks plain LDS loads back next to their use at this
-    // register pressure, so the reads and their counted waits are inline asm: LDS returns data in
-    // order, hence before step s may start at most the two younger reads (s+1, s+2) may be pending.
-    // The wait statement takes the fragment as an in/out operand so that the MFMAs cannot be
-    // scheduled above it.  No other LGKM operation is issued inside this block.  The next tile's DMA
-    // pieces are issued one per KS/PPW k-steps, in the shadow of the MFMAs.
-    u32x4m a0, a1, a2;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(a0) : "v"(a_addr[0]));
-    asm volatile("ds_read_b128 %0, %1" : "=v"(a1) : "v"(a_addr[1]));
+        for (int p = 0; p < PPW; ++p) issue_piece(next_rsrc, buf2, p);
+      }
+#ifdef DEWI_MFMA_STAMPS
+      const uint64_t sp2 = ST_NOW();
+      st_vm += sp1 - sp0;
+      st_dma += sp2 - sp1;
+#endif
+      if (filter) epilogue(acc, filter_tile);
+    };
+
+#ifdef DEWI_MFMA_STAMPS
+    const uint64_t st_b = ST_NOW();
+#endif
+    if (deferred) side_phase(prev >= 0, prev);
+#ifdef DEWI_MFMA_STAMPS
+    const uint64_t st_c = ST_NOW();
+#endif
+    if (DEWI_MFMA_PRIO) __builtin_amdgcn_s_setprio(3);   // the matrix block wins issue arbitration against the other wave's epilogue
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      if (s + 2 < KS) {
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a2) : "v"(a_addr[(s + 2) & 7]), "n"(256 * ((s + 2) >> 3)));
-        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a0));
-      } else if (s + 1 < KS) {
-        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a0));
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0));
-      }
-      const bf16x8 a = __builtin_bit_cast(bf16x8, a0);
+      u32x4m& cur = ring[s % (kAhead + 1)];
+      if (s + kAhead < KS) read_fragment(ring[(s + kAhead) % (kAhead + 1)], s + kAhead);
+      asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(cur) : "n"((KS - 1 - s) < kAhead ? (KS - 1 - s) : kAhead));
+      const bf16x8 a = __builtin_bit_cast(bf16x8, cur);
       if (DEWI_MFMA_ABLATE != 3) {
 #pragma unroll
-        for (int b = 0; b < kQB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[b][s], acc[b], 0, 0, 0);
+        for (int b = 0; b < kQB; ++b) {
+          // the first k-step accumulates onto a literal zero: no 16 v_mov per tile to clear the accumulator
+          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[b][s], s == 0 ? zero : acc[b], 0, 0, 0);
+        }
       } else {
         asm volatile("" ::"v"(a));
       }
-      if (s % (KS / PPW) == 1 && has_next2) issue_piece(next_rsrc, buf2, s / (KS / PPW));
-      a0 = a1;
-      a1 = a2;
     }
 
-    if (!deferred) epilogue(acc, i);
+    if (DEWI_MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
+#ifdef DEWI_MFMA_STAMPS
+    asm volatile("" ::"v"(acc[0]));
+    const uint64_t st_w = ST_NOW();
+    const uint64_t st_d = st_w;
+#endif
+    if (!deferred) side_phase(true, i);
+#ifdef DEWI_MFMA_STAMPS
+    const uint64_t st_e = ST_NOW();
+    st_wait += st_b - st_a;
+    st_mfma += st_w - st_c;
+    st_epi += (st_c - st_b) + (st_e - st_d);
+    ++st_tiles;
+#endif
     prev = i;
 #pragma unroll
     for (int j = 0; j < 8; ++j) a_addr[j] = buf == kTileBufs - 1 ? a_addr[j] - (kTileBufs - 1) * TILE_BYTES : a_addr[j] + TILE_BYTES;
     buf = buf == kTileBufs - 1 ? 0 : buf + 1;
   }
   if (deferred && prev >= 0) epilogue(acc, prev);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef DEWI_MFMA_STAMPS
+  if (!DENSE && blockIdx.x == 3 && lane == 0)
+    printf("wave %d tiles %llu total %llu dma-issue/tile %llu vmwait/tile %llu | barrier %llu mfma %llu epilogue %llu (cycles per tile: %llu / %llu / %llu)\n", wave, (unsigned long long)st_tiles, (unsigned long long)(ST_NOW() - st_t0), (unsigned long long)(st_dma / st_tiles), (unsigned long long)(st_vm / st_tiles),
+           (unsigned long long)st_wait,
+           (unsigned long long)st_mfma, (unsigned long long)st_epi, (unsigned long long)(st_wait / st_tiles),
+           (unsigned long long)(st_mfma / st_tiles), (unsigned long long)(st_epi / st_tiles));
+#endif
   if constexpr (!DENSE) {
 #pragma unroll
     for (int b = 0; b < kQB; ++b) {
       const uint32_t seg_q = (static_cast<uint32_t>(blockIdx.x) * 2 + h) * kQueriesPerPass + (32 * kQB * wave + 32 * b + r);
-      cnt[seg_q] = slot[b] - seg_q * static_cast<uint32_t>(out_stride);
+      cnt[seg_q] = (off[b] >> 3) - seg_q * static_cast<uint32_t>(out_stride);
     }
   }
 #endif
