@@ -172,36 +172,47 @@ def main():
                 pipe.submit(qs[j], oi[j], osc[j])
             pipe.drain()
     else:
-        # Sharded throughput loop.  scan stream: scans back to back.  Current (finish) stream: candidate
-        # records of query i, its all-gather (async, RCCL's stream), and — `depth`-1 queries later — the
-        # merge.  Up to depth-1 all-gathers are in flight behind the scans.
+        # Sharded throughput loop.  Scans alternate between two scan streams (the tail of one overlaps the
+        # ramp of the next: at 125 K rows per GPU a lone scan spends a quarter of its 68 us ramping up and
+        # merging).  Candidate records of G consecutive queries share ONE all-gather and ONE merge launch:
+        # a torch.distributed collective costs ~26 us of host time however small it is, and with 125 K rows
+        # per GPU the host, not the GPU, was pacing the loop (65 us of submission per query).  Up to
+        # depth-1 groups are in flight behind the scans.
         depth = 3
         nbuf = depth + 1
+        G = max(1, int(os.environ.get("DEWI_BENCH_GROUP", "4")))
+        n_distinct -= n_distinct % G          # groups never wrap around the query ring
         fin = torch.cuda.Stream()
         torch.cuda.set_stream(fin)          # torch.distributed orders collectives against the current stream
         pipe = eng.PipelinedSearcher(corpus, k, eta, 0.0, n_queries=B, n_candidates=c, finish_stream=fin,
-                                     depth=int(os.environ.get("DEWI_BENCH_WS_DEPTH", "4")))
-        send = [torch.empty((B, c, 4), dtype=torch.int32, device=device) for _ in range(nbuf)]
-        recv = [torch.empty((world, B, c, 4), dtype=torch.int32, device=device) for _ in range(nbuf)]
-        send_flat = [t.view(-1) for t in send]
-        recv_flat = [t.view(-1) for t in recv]
+                                     depth=max(int(os.environ.get("DEWI_BENCH_WS_DEPTH", "4")), 2 * G),
+                                     scan_streams=int(os.environ.get("DEWI_BENCH_SCAN_STREAMS", "2")))
+        send = [torch.empty((G, B, c, 4), dtype=torch.int32, device=device) for _ in range(nbuf)]
+        recv = [torch.empty((world * G * B * c * 4,), dtype=torch.int32, device=device) for _ in range(nbuf)]
         from collections import deque
+
+        def finish_group(work, j0, g, s):
+            work.wait()
+            lists = recv[s][: world * g * B * c * 4].view(world, g * B, c, 4)
+            eng.merge_rerank_device(lists, c, k, eta, 0.0, out_ids[j0:j0 + g].view(g * B, k), out_sc[j0:j0 + g].view(g * B, k))
 
         def run(first, count):
             inflight = deque()
-            for i in range(first, first + count):
-                j, s = i % n_distinct, i % nbuf
-                pipe.submit(qs[j], out_records=send[s])
-                work = dist.all_gather_into_tensor(recv_flat[s], send_flat[s], async_op=True)
-                inflight.append((work, j, s))
+            i, n_group = first, 0
+            while i < first + count:
+                j0 = i % n_distinct
+                g = min(G, first + count - i, n_distinct - j0)
+                s = n_group % nbuf
+                for u in range(g):
+                    pipe.submit(qs[j0 + u], out_records=send[s][u])
+                work = dist.all_gather_into_tensor(recv[s][: world * g * B * c * 4], send[s][:g].view(-1), async_op=True)
+                inflight.append((work, j0, g, s))
                 if len(inflight) >= depth:
-                    pw, pj, ps = inflight.popleft()
-                    pw.wait()
-                    eng.merge_rerank_device(recv[ps], c, k, eta, 0.0, oi[pj], osc[pj])
+                    finish_group(*inflight.popleft())
+                i += g
+                n_group += 1
             while inflight:
-                pw, pj, ps = inflight.popleft()
-                pw.wait()
-                eng.merge_rerank_device(recv[ps], c, k, eta, 0.0, oi[pj], osc[pj])
+                finish_group(*inflight.popleft())
             pipe.drain()
 
     def barrier():
@@ -255,7 +266,7 @@ def main():
                                f"brute-force cosine kNN + DEWI re-rank (BASELINE.json configs[1])",
                    "docs": total_rows, "dim": args.dim, "k": k, "eta": eta, "batch": B, "candidates": c,
                    "parallelism": f"doc-id shards x{world} + RCCL all-gather" if sharded else "single GPU",
-                   "queries_in_flight": 1 if (serial and not sharded) else (3 if sharded else 2),
+                   "queries_in_flight": 1 if (serial and not sharded) else (3 * G if sharded else 2),
                    "rows_per_gpu": n_local},
         "roofline": {"bound": "hbm", "kernel": "scan_rows_f32", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -287,6 +298,27 @@ def main():
         result["sharded_parity"] = {"queries_checked": n_chk, "mismatches_vs_single_gpu": bad}
         if bad:
             print(f"SHARDED PARITY FAIL: {bad}/{n_chk} queries differ from the single-GPU search", file=sys.stderr)
+
+    # ------------------------------------------------------------------ p50 latency of the sharded path
+    # One query at a time, nothing in flight: scan + select on every rank, all-gather, merge, host sync.
+    # Every rank runs the loop (the all-gather is a collective); rank 0 reports.
+    if sharded and args.latency_queries > 0:
+        n_lat = min(args.latency_queries, n_distinct, 300)
+        barrier()
+        lat = []
+        for j in range(n_lat):
+            t1 = time.perf_counter()
+            pipe.submit(qs[j], out_records=send[0][0])
+            dist.all_gather_into_tensor(recv[0][: world * B * c * 4], send[0][:1].view(-1))
+            eng.merge_rerank_device(recv[0][: world * B * c * 4].view(world, B, c, 4), c, k, eta, 0.0, oi[j], osc[j])
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t1)
+        pipe.drain()
+        lat = np.array(lat[5:]) * 1e3
+        if rank == 0 and len(lat):
+            result["p50_latency_ms"] = round(float(np.percentile(lat, 50)), 4)
+            result["p99_latency_ms"] = round(float(np.percentile(lat, 99)), 4)
+            result["latency_path"] = "device-resident query -> scan+select per shard -> RCCL all-gather -> merge -> host sync"
 
     # ------------------------------------------------------------------ p50 latency through the API
     if rank == 0 and world == 1 and args.latency_queries > 0:

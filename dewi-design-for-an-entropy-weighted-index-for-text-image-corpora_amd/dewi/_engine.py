@@ -228,7 +228,7 @@ class PipelinedSearcher:
     """
 
     def __init__(self, corpus: DeviceCorpus, k: int, eta: float, entropy_pref: float, n_queries: int = 1,
-                 n_candidates: Optional[int] = None, finish_stream=None, depth: int = 2):
+                 n_candidates: Optional[int] = None, finish_stream=None, depth: int = 2, scan_streams: int = 1):
         torch = _torch()
         self.corpus = corpus
         self.k, self.eta, self.pref, self.b = int(k), float(eta), float(entropy_pref), int(n_queries)
@@ -239,7 +239,12 @@ class PipelinedSearcher:
             raise nat.NativeLibraryError("dewi_knn_workspace_bytes returned 0: " + nat.last_error())
         self._need = need
         with torch.cuda.device(corpus.device):
-            self.scan_stream = torch.cuda.Stream()
+            # scan_streams > 1: consecutive scans alternate between streams, so the tail of one (block merge,
+            # last workgroups) overlaps the ramp of the next (query preparation) — small shards only
+            # (alternating priorities: streams of different priority never share a hardware queue, so the
+            # overlap does not depend on how the runtime happens to map streams to queues)
+            self._scan_streams = [torch.cuda.Stream(priority=-(j % 2)) for j in range(max(1, int(scan_streams)))]
+            self.scan_stream = self._scan_streams[0]
             self.finish_stream = finish_stream if finish_stream is not None else torch.cuda.Stream()
             self.depth = max(2, int(depth))   # workspaces in rotation = scans that may run ahead of their finish
             self._ws = [torch.empty(need, dtype=torch.uint8, device=corpus.device) for _ in range(self.depth)]
@@ -249,7 +254,8 @@ class PipelinedSearcher:
         self._elem = 1 if corpus.is_bf16 else 0
         self._space = nat.SPACE_CODES[corpus.space]
         self._emb, self._dewi, self._ent = nat.ptr(corpus.emb), nat.ptr(corpus.dewi32), nat.ptr(corpus.ent32)
-        self._s_scan, self._s_fin = int(self.scan_stream.cuda_stream), int(self.finish_stream.cuda_stream)
+        self._s_scans = [int(st.cuda_stream) for st in self._scan_streams]
+        self._s_fin = int(self.finish_stream.cuda_stream)
 
     def submit(self, q_dev, out_ids=None, out_scores=None, out_records=None) -> None:
         """Enqueue one query batch.  Final results go to (out_ids, out_scores); with ``out_records``
@@ -258,13 +264,15 @@ class PipelinedSearcher:
         slot = i % self.depth
         self._i = i + 1
         c = self.corpus
+        which = i % len(self._scan_streams)
+        scan_stream = self._scan_streams[which]
         if i >= self.depth:
-            self.scan_stream.wait_event(self._finish_done[slot])       # workspace `slot` is free again
+            scan_stream.wait_event(self._finish_done[slot])            # workspace `slot` is free again
         rc = self._lib.dewi_knn_scan(self._emb, self._elem, c.n_rows, c.dim, q_dev.data_ptr(), self.b, self.c,
-                                     self._space, self._ws[slot].data_ptr(), self._need, self._s_scan)
+                                     self._space, self._ws[slot].data_ptr(), self._need, self._s_scans[which])
         if rc:
             nat.check(rc)
-        self._scan_done[slot].record(self.scan_stream)
+        self._scan_done[slot].record(scan_stream)
         self.finish_stream.wait_event(self._scan_done[slot])
         if out_records is None:
             rc = self._lib.dewi_knn_finish(self._ws[slot].data_ptr(), self._need, self._elem, c.n_rows, c.dim, self.b, self.c,
@@ -279,7 +287,8 @@ class PipelinedSearcher:
         self._finish_done[slot].record(self.finish_stream)
 
     def drain(self) -> None:
-        self.scan_stream.synchronize()
+        for st in self._scan_streams:
+            st.synchronize()
         self.finish_stream.synchronize()
 
 
