@@ -402,6 +402,35 @@ int dewi_knn_candidates(const void* d_E, int elem_type, int64_t n_rows, int dim,
   if (rc) return rc;
   // a shard can contribute at most n_rows candidates; the rest of each list is padding
   const int c_local = n_candidates < n_rows ? n_candidates : static_cast<int>(n_rows);
+  if (elem_type == 1 && g_tuning.mfma != 0 && c_local == n_candidates &&
+      dewi::mfma_path_supported(n_rows, dim, n_queries, n_candidates, space)) {
+    // many queries over a bf16 shard: matrix-core path; an overflowed query's records carry id -2
+    const dewi::MfmaLayout M = dewi::plan_mfma(n_rows, dim, n_queries, n_candidates, dev.cus);
+    if (!d_workspace || workspace_bytes < M.total)
+      return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, M.total);
+    char* wsm = static_cast<char*>(d_workspace);
+    hipError_t e;
+    {
+      ScanTimer timer(stream);
+      e = dewi::launch_mfma_bf16(M, static_cast<const uint16_t*>(d_E), n_rows, dim, d_Q, n_queries, n_candidates, space, wsm,
+                                 dev.cus, stream);
+    }
+    if (e != hipSuccess) return hip_fail(e, "mfma scan launch");
+    const dewi::RerankParams rp0 = make_rerank(0.0, 0.0);
+    for (int g = 0; g < M.groups; ++g) {
+      const int q0 = g * 256;
+      const int nq = n_queries - q0 < 256 ? n_queries - q0 : 256;
+      const dewi::SegmentLayout seg{M.n_seg, M.seg_cap, 1, static_cast<int64_t>(256) * M.seg_cap, 256, 8192};
+      const uint64_t* keys = reinterpret_cast<const uint64_t*>(wsm + M.cand_off) +
+                             static_cast<int64_t>(g) * M.n_seg * 256 * M.seg_cap;
+      const uint32_t* counts = reinterpret_cast<const uint32_t*>(wsm + M.cnt_off) + static_cast<int64_t>(g) * M.n_seg * 256;
+      e = dewi::launch_select_rerank(keys, 0, 0, nq, n_candidates, 0, rp0, d_dewi32, d_ent32, id_offset, nullptr, nullptr,
+                                     d_out + static_cast<int64_t>(q0) * n_candidates, counts, seg, stream);
+      if (e != hipSuccess) break;
+    }
+    if (e != hipSuccess) return hip_fail(e, "select (candidates) launch");
+    return DEWI_OK;
+  }
   const KnnLayout L = layout_knn(n_rows, dim, elem_type ? 2 : 4, n_queries, c_local, dev.cus);
   if (!d_workspace || workspace_bytes < L.total)
     return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, L.total);

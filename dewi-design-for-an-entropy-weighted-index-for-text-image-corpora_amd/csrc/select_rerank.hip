@@ -335,6 +335,17 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(
     __shared__ uint32_t seg_base[kSelectThreads], seg_cnt[kSelectThreads];
     const uint32_t cap = static_cast<uint32_t>(seg.cap);
     auto refuse = [&]() {
+      if (out_cand != nullptr) {   // shard mode: every record of this query carries the marker id -2
+        for (int j = tid; j < n_candidates; j += nt) {
+          dewi_candidate rec;
+          rec.sim = __builtin_nanf("");
+          rec.dewi = 0.f;
+          rec.ent = 0.f;
+          rec.id = -2;
+          out_cand[static_cast<int64_t>(q) * n_candidates + j] = rec;
+        }
+        return;
+      }
       for (int j = tid; j < k; j += nt) {
         out_ids[static_cast<int64_t>(q) * k + j] = -1;
         out_scores[static_cast<int64_t>(q) * k + j] = __builtin_nanf("");
@@ -472,7 +483,10 @@ __global__ __launch_bounds__(kSelectThreads) void merge_rerank_kernel(const dewi
   const int q = static_cast<int>(blockIdx.x);
   const int m = n_lists * list_len;
   const int p2 = pow2_at_least(m);
-  if (tid == 0) sh.count = 0;
+  if (tid == 0) {
+    sh.count = 0;
+    sh.total = 0;
+  }
   __syncthreads();
   const bool small = m <= kRankSortMax;   // the usual case (8 shards x 2k records): one ranking pass
   for (int t = tid; t < p2; t += nt) {
@@ -482,6 +496,7 @@ __global__ __launch_bounds__(kSelectThreads) void merge_rerank_kernel(const dewi
       const int l = t / list_len, j = t % list_len;
       const int64_t at = (static_cast<int64_t>(l) * n_queries + q) * list_len + j;
       const dewi_candidate rec = lists[at];
+      if (rec.id == -2) sh.total = 1;   // that shard's batched path overflowed: the query is unanswered
       if (rec.id >= 0) {
         key = make_key(rec.sim, static_cast<uint32_t>(rec.id));
         src = static_cast<uint32_t>(t);
@@ -495,8 +510,15 @@ __global__ __launch_bounds__(kSelectThreads) void merge_rerank_kernel(const dewi
       sh.val[t] = src;
     }
   }
+  __syncthreads();
+  if (sh.total) {   // same marker as the single-device batched path: ids -1, the caller re-runs the query
+    for (int j = tid; j < k; j += nt) {
+      out_ids[static_cast<int64_t>(q) * k + j] = -1;
+      out_scores[static_cast<int64_t>(q) * k + j] = __builtin_nanf("");
+    }
+    return;
+  }
   if (small) {
-    __syncthreads();
     for (int t = tid; t < m; t += nt) {
       const uint64_t mine = sh.sel2[t];
       int rank = 0;

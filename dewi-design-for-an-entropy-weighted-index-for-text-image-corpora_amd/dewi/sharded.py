@@ -100,11 +100,24 @@ class ShardedSearcher:
         if k > self.n_total:
             raise ValueError(f"kth(={self.n_total - k}) out of bounds ({self.n_total})")   # as NumPy in the reference
         c = self.n_candidates(k)
-        recs = self._scan(queries, c)
-        lists = self.exchange(recs)
-        ids, scores = self._merge(lists, c, k, float(eta), float(entropy_pref))
         to_np = lambda t: t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)  # noqa: E731
-        return to_np(ids), to_np(scores)
+
+        def one_pass(q):
+            lists = self.exchange(self._scan(q, c))
+            ids, scores = self._merge(lists, c, k, float(eta), float(entropy_pref))
+            return to_np(ids), to_np(scores)
+
+        ids, scores = one_pass(queries)
+        # A bf16 shard's batched matrix-core path marks a query whose survivor buffer overflowed
+        # (adversarial corpora); the merge then returns id -1 for it on EVERY rank, so all ranks agree on
+        # the retry: that query alone (batch 1 takes the exact small-batch kernels).
+        unanswered = np.nonzero(ids[:, 0] < 0)[0]
+        if len(unanswered):
+            ids, scores = ids.copy(), scores.copy()
+            q2 = np.atleast_2d(to_np(queries))
+            for b in unanswered:
+                ids[b], scores[b] = (a[0] for a in one_pass(q2[b:b + 1]))
+        return ids, scores
 
 
 def build_local_shard(rows: np.ndarray, dewi: Sequence[float], ht_mean: Sequence[float], hi_mean: Sequence[float],

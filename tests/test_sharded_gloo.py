@@ -179,3 +179,56 @@ def test_two_ranks_on_one_gpu_equal_single_device():
         ids, sc = whole.search(Q, k, 0.3, 0.2)
         for r in (0, 1):
             assert np.array_equal(ret[r][k][0], ids) and np.array_equal(ret[r][k][1], sc)
+
+
+# ---- GPU: bf16 shards with a query batch large enough for the matrix-core path ---------------------
+_BF16 = dict(n=140_000, d=128, b=40, k=10)          # 70 K rows per shard (>= 64 K), 40 queries (>= 16)
+
+
+def _bf16_inputs(duplicates):
+    import dewi_oracle as orc
+    n, d, b = _BF16["n"], _BF16["d"], _BF16["b"]
+    raw = orc.synth_corpus(n, d, seed=41)
+    cols = orc.synth_payload_columns(n, seed=41)
+    Q = orc.synth_queries(b, d, seed=42)
+    if duplicates:
+        raw[100_000:140_000] = raw[7]                # 40 000 copies of row 7, all inside shard 1
+        Q[5] = raw[7]                                # query 5 overflows shard 1's survivor buffer
+    return raw, cols, Q
+
+
+def _gpu_worker_bf16(rank, world, port, duplicates, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dewi.sharded import ShardedSearcher, build_local_shard
+        torch.cuda.set_device(0)
+        raw, cols, Q = _bf16_inputs(duplicates)
+        local = build_local_shard(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"], rank, world).to_bf16()
+        s = ShardedSearcher(local, local.n_rows)
+        out = {"final": s.search(Q, _BF16["k"], 0.3, 0.2)}
+        if duplicates:   # the raw records of the overflowed query carry the marker on the shard that overflowed
+            recs = local.candidates_device(local.stage_queries(Q), s.n_candidates(_BF16["k"])).cpu().numpy()
+            out["marker"] = (int(recs[5, 0, 3]), int(recs[4, 0, 3]))
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("duplicates", [False, True])
+def test_two_bf16_shards_batched_path_equal_single_device(duplicates):
+    from dewi import _engine as eng
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_gpu_worker_bf16, args=(2, _free_port(), duplicates, ret), nprocs=2, join=True)
+    raw, cols, Q = _bf16_inputs(duplicates)
+    whole = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"]).to_bf16()
+    ids, sc = whole.search(Q, _BF16["k"], 0.3, 0.2)     # single device: same kernels per row, exact selection
+    for r in (0, 1):
+        assert np.array_equal(ret[r]["final"][0], ids), r
+        assert np.array_equal(ret[r]["final"][1], sc), r
+    if duplicates:
+        assert ret[1]["marker"][0] == -2 and ret[1]["marker"][1] >= 0     # shard 1 overflowed on query 5 only
+        assert ret[0]["marker"][0] >= 0                                   # shard 0 answered it
+        assert ids[5, 0] == 7 or ids[5, 0] >= 100_000                    # the duplicated document wins
