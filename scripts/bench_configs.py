@@ -63,6 +63,16 @@ ie = te * 0.5 + torch.randn((n, d), generator=g, device=dev)
 ih = torch.empty(n, device=dev)
 t = timed(lambda: nat.check(lib.dewi_row_cosine_f32(nat.ptr(te), nat.ptr(ie), nat.ptr(ih), n, d, nat.stream_ptr())))
 out["C5_I_hat_row_cosine"] = {"ms": round(t * 1e3, 4), "hbm_GBps": round(2 * n * d * 4 / t / 1e9, 1)}
+from dewi.signals import redundancy_top1  # noqa: E402
+nr = 262_144
+t_h, i_h = te[:nr].cpu().numpy(), ie[:nr].cpu().numpy()
+redundancy_top1(t_h[:4096], i_h[:4096])          # warm-up (library load, workspaces)
+t0 = time.perf_counter()
+red = redundancy_top1(t_h, i_h)                   # bf16 corpus + batched matrix-core path, host arrays in and out
+t = time.perf_counter() - t0
+out["C5_redundancy_top1_262144x512"] = {"s": round(t, 4), "self_join_TFLOPs": round(2 * nr * nr * d / t / 1e12, 1),
+                                        "note": "host fp32 arrays in, host fp32 out (includes H2D of 2 x 0.5 GB, normalise, bf16 convert)"}
+del t_h, i_h
 sig = torch.rand((7, n), generator=g, device=dev)
 med = torch.empty(7, device=dev)
 mad = torch.empty(7, device=dev)
