@@ -184,22 +184,24 @@ class DeviceCorpus:
         torch = _torch()
         with torch.cuda.device(self.device):
             q = self.stage_queries(queries)
-            # Results come back through cached device + pinned host buffers: two async copies and ONE
-            # stream synchronisation instead of two blocking pageable copies (p50 at 1 M x 768: -25 us).
+            # Results come back through cached device + pinned host buffers: one async copy and ONE stream
+            # synchronisation instead of two blocking pageable copies.
             b, kk = int(q.shape[0]), max(int(k), 0)
             io = self._io.get((b, kk))
             if io is None:
                 if len(self._io) > 8:
                     self._io.clear()
-                io = (torch.empty((b, kk), dtype=torch.int64, device=self.device),
-                      torch.empty((b, kk), dtype=torch.float32, device=self.device),
-                      torch.empty((b, kk), dtype=torch.int64, pin_memory=True),
-                      torch.empty((b, kk), dtype=torch.float32, pin_memory=True))
+                # ids (int64) and scores (fp32) share one allocation, so that they return in one copy
+                n_el = b * kk
+                dbuf = torch.empty(n_el * 12, dtype=torch.uint8, device=self.device)
+                hbuf = torch.empty(n_el * 12, dtype=torch.uint8, pin_memory=True)
+                io = (dbuf[: n_el * 8].view(torch.int64).view(b, kk), dbuf[n_el * 8:].view(torch.float32).view(b, kk),
+                      hbuf[: n_el * 8].view(torch.int64).view(b, kk), hbuf[n_el * 8:].view(torch.float32).view(b, kk),
+                      dbuf, hbuf)
                 self._io[(b, kk)] = io
             if kk > 0:
-                ids, scores = self.search_device(q, k, eta, entropy_pref, io[0], io[1], candidates=candidates)
-                io[2].copy_(ids, non_blocking=True)
-                io[3].copy_(scores, non_blocking=True)
+                self.search_device(q, k, eta, entropy_pref, io[0], io[1], candidates=candidates)
+                io[5].copy_(io[4], non_blocking=True)
                 torch.cuda.current_stream().synchronize()
             ids_h = io[2].numpy().copy()
             scores_h = io[3].numpy().copy()
