@@ -13,6 +13,10 @@
 // in flight per wave, 8 waves per CU — the shape that measured best on the fp32 kernel.
 #include "scan_common.hpp"
 
+#ifndef DEWI_BF16_PAIRS
+#define DEWI_BF16_PAIRS 2
+#endif
+
 namespace dewi {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -170,7 +174,25 @@ __global__ __launch_bounds__(kScanThreads) void scan_rows_bf16(const uint16_t* _
 
   const u32x4* Ev = reinterpret_cast<const u32x4*>(E);
   const int64_t n_pairs = n_rows >> 1;
-  for (int64_t p = gwave; p < n_pairs; p += n_waves) {
+  int64_t p = gwave;
+  // DEWI_BF16_PAIRS row pairs per trip: that many x H independent 1 KiB loads are in flight before the
+  // first reduction starts (a bf16 row pair carries half the bytes of an fp32 row per reduction, so one
+  // pair per trip left the memory pipe waiting on the DPP chains: 230 us per 1 M x 768 pass; two: 220).
+  constexpr int P = DEWI_BF16_PAIRS;
+  if constexpr (P > 1) {
+    for (; p + (P - 1) * n_waves < n_pairs; p += P * n_waves) {
+      u32x4 v[P][H];
+#pragma unroll
+      for (int u = 0; u < P; ++u) {
+        const u32x4* base = Ev + (p + u * n_waves) * (2 * UPR) + lane;
+#pragma unroll
+        for (int j = 0; j < H; ++j) v[u][j] = load_u4<NT>(base + 64 * j);
+      }
+#pragma unroll
+      for (int u = 0; u < P; ++u) consume_pair(v[u], 2 * (p + u * n_waves), true);
+    }
+  }
+  for (; p < n_pairs; p += n_waves) {
     const u32x4* base = Ev + p * (2 * UPR) + lane;
     u32x4 v[H];
 #pragma unroll
