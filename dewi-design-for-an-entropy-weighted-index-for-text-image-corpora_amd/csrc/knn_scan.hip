@@ -112,8 +112,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_rows_f32(const float* __res
 
   // Full R-row groups.  Deliberately NOT software-pipelined and with a small R: on MI355X the scan
   // is fastest with only ~24 KiB of loads in flight per CU (8 waves x one 3 KiB row; 1M x 768:
-  // R=1 0.434 ms, R=2 0.449, R=8 0.459, prefetching the next group 0.441) — more outstanding
-  // requests lower the achieved HBM rate instead of raising it.
+  // R=1 0.434 ms, R=2 0.449, R=8 0.459, prefetching the next group 0.441; R=2 with the two rows n_waves
+  // apart, so that the chip still sweeps one window: 0.437 vs 0.429) — more outstanding requests lower
+  // the achieved HBM rate instead of raising it.
   const int64_t n_groups = n_rows / R;
   for (int64_t g = gwave; g < n_groups; g += n_waves) {
     const int64_t row0 = g * R;
