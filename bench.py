@@ -274,6 +274,13 @@ def main():
                      "launches_timed": scan_launches},
     }
 
+    if sharded:
+        # Two scans are in flight at a time on this path (alternating scan streams), so a launch's duration
+        # (what `achieved` is computed from) is about twice its share of the memory pipe; the loop-level
+        # rate says what the GPU actually streamed.
+        result["roofline"]["scans_in_flight"] = int(os.environ.get("DEWI_BENCH_SCAN_STREAMS", "2"))
+        result["roofline"]["effective_GBps_per_gpu"] = round(algo_bytes * args.steps / elapsed / 1e9, 1)
+
     # ------------------------------------------------------------------ sharded result == single-GPU result
     if rank == 0 and sharded:
         if world > 1:
