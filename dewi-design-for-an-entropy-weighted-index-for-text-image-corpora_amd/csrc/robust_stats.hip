@@ -68,17 +68,27 @@ __device__ __forceinline__ bool digit_of(uint32_t key, uint32_t prefix, uint32_t
 }
 
 // grid (blocks_per_signal, n_signals).  MAD == true: keys are ord(|x - med[s]|), fp32 subtraction.
+// Launch shape: few fat workgroups (kHistThreads threads, about one workgroup per CU over all signals),
+// 16-byte loads.  A workgroup pays for zeroing and flushing its 2 x 2048 LDS bins once, and in the
+// second pass nearly every bin is non-zero: with 1 715 workgroups of 256 threads the flush alone was
+// 7 M global atomics per pass (27 us); 224 workgroups of 1 024 threads flush 0.9 M.
+constexpr int kHistThreads = 1024;
+
 template <int PASS, bool MAD>
-__global__ __launch_bounds__(kFitThreads) void fit_hist_kernel(const float* __restrict__ S, int64_t n, int64_t ld,
-                                                               const float* __restrict__ med,
-                                                               const FitState* __restrict__ state,
-                                                               uint32_t* __restrict__ hist,
-                                                               uint32_t* __restrict__ nan_count) {
-  __shared__ uint32_t lh[2][kBins];
+__global__ __launch_bounds__(kHistThreads) void fit_hist_kernel(const float* __restrict__ S, int64_t n, int64_t ld,
+                                                                const float* __restrict__ med,
+                                                                const FitState* __restrict__ state,
+                                                                uint32_t* __restrict__ hist,
+                                                                uint32_t* __restrict__ nan_count) {
+  // PASS 0: both problems of a signal (lower / upper middle rank) see the same keys, and real signals
+  // crowd into a few dozen of the 2048 top-bit bins: ONE histogram, kept in four copies selected by
+  // lane so that the lanes of a wave serialise on a bin four times less, written to both problems at
+  // the flush.  Later passes: one histogram per problem (the prefixes may differ), bins well spread.
+  __shared__ uint32_t lh[4][kBins];
   __shared__ uint32_t lnan;
   const int s = static_cast<int>(blockIdx.y);
   const int tid = static_cast<int>(threadIdx.x);
-  for (int i = tid; i < 2 * kBins; i += kFitThreads) (&lh[0][0])[i] = 0;
+  for (int i = tid; i < 4 * kBins; i += kHistThreads) (&lh[0][0])[i] = 0;
   if (tid == 0) lnan = 0;
   __syncthreads();
   const float* col = S + static_cast<int64_t>(s) * ld;
@@ -89,24 +99,55 @@ __global__ __launch_bounds__(kFitThreads) void fit_hist_kernel(const float* __re
     pre1 = state[2 * s + 1].prefix;
   }
   uint32_t nans = 0;
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * kFitThreads;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kFitThreads + tid; i < n; i += stride) {
-    float x = col[i];
+  auto take = [&](float x) {
     if constexpr (MAD) x = __builtin_fabsf(__fsub_rn(x, m));
     if constexpr (PASS == 0) nans += (x != x) ? 1u : 0u;
     const uint32_t key = ord_f32(x);
     uint32_t d;
-    if (digit_of<PASS>(key, pre0, d)) atomicAdd(&lh[0][d], 1u);
-    if (digit_of<PASS>(key, pre1, d)) atomicAdd(&lh[1][d], 1u);
+    if constexpr (PASS == 0) {
+      digit_of<0>(key, 0u, d);
+      atomicAdd(&lh[tid & 3][d], 1u);
+    } else {
+      if (digit_of<PASS>(key, pre0, d)) atomicAdd(&lh[0][d], 1u);
+      if (digit_of<PASS>(key, pre1, d)) atomicAdd(&lh[1][d], 1u);
+    }
+  };
+  // head (to 16-byte alignment), 16-byte body, tail — every element exactly once
+  const int64_t mis = (reinterpret_cast<uintptr_t>(col) & 15) / 4;
+  int64_t head = mis ? 4 - mis : 0;
+  head = head < n ? head : n;
+  const int64_t n4 = (n - head) / 4;
+  const int64_t gtid = static_cast<int64_t>(blockIdx.x) * kHistThreads + tid;
+  const int64_t gstride = static_cast<int64_t>(gridDim.x) * kHistThreads;
+  if (gtid < head) take(col[gtid]);
+  const f32x4* body = reinterpret_cast<const f32x4*>(col + head);
+  for (int64_t i = gtid; i < n4; i += gstride) {
+    const f32x4 v = body[i];
+    take(v.x);
+    take(v.y);
+    take(v.z);
+    take(v.w);
   }
+  const int64_t tail0 = head + 4 * n4;
+  if (tail0 + gtid < n) take(col[tail0 + gtid]);   // fewer than 4 elements
   if constexpr (PASS == 0) {
     if (nans) atomicAdd(&lnan, nans);
   }
   __syncthreads();
   uint32_t* gh = hist + static_cast<int64_t>(2 * s) * kBins;
-  for (int i = tid; i < 2 * kBins; i += kFitThreads) {
-    const uint32_t v = (&lh[0][0])[i];
-    if (v) atomicAdd(&gh[i], v);
+  if constexpr (PASS == 0) {
+    for (int i = tid; i < kBins; i += kHistThreads) {
+      const uint32_t v = lh[0][i] + lh[1][i] + lh[2][i] + lh[3][i];
+      if (v) {
+        atomicAdd(&gh[i], v);
+        atomicAdd(&gh[kBins + i], v);
+      }
+    }
+  } else {
+    for (int i = tid; i < 2 * kBins; i += kHistThreads) {
+      const uint32_t v = (&lh[0][0])[i];
+      if (v) atomicAdd(&gh[i], v);
+    }
   }
   if constexpr (PASS == 0) {
     if (tid == 0 && lnan) atomicAdd(&nan_count[s], lnan);
@@ -204,12 +245,13 @@ hipError_t launch_fit_hist(const float* S, int64_t n, int64_t ld, int n_signals,
   uint32_t* hist = hist_of(w, n_signals, phase, pass);
   FitState* state = w.state + phase * P;
   uint32_t* nanc = w.nan_count + phase * n_signals;
-  int64_t bx = (n + kFitThreads * 16 - 1) / (kFitThreads * 16);
+  int64_t bx = (n + kHistThreads * 16 - 1) / (kHistThreads * 16);
   if (bx < 1) bx = 1;   // an empty shard still launches (and contributes an all-zero histogram)
-  if (bx > 512) bx = 512;
+  const int64_t per_signal = (256 + n_signals - 1) / n_signals;   // ~one workgroup per CU over all signals
+  if (bx > per_signal) bx = per_signal;
   const dim3 grid(static_cast<unsigned>(bx), static_cast<unsigned>(n_signals));
 #define DEWI_HIST(PASS, MAD) \
-  hipLaunchKernelGGL((fit_hist_kernel<PASS, MAD>), grid, dim3(kFitThreads), 0, stream, S, n, ld, med, state, hist, nanc)
+  hipLaunchKernelGGL((fit_hist_kernel<PASS, MAD>), grid, dim3(kHistThreads), 0, stream, S, n, ld, med, state, hist, nanc)
   if (phase == 0) {
     if (pass == 0) DEWI_HIST(0, false); else if (pass == 1) DEWI_HIST(1, false); else DEWI_HIST(2, false);
   } else {
