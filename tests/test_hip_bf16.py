@@ -61,3 +61,29 @@ def test_bf16_sharded_equals_whole():
         lists.append(sh.candidates_device(qd, 2 * k))
     ids, sc = eng.merge_rerank_device(torch.stack(lists), 2 * k, k, 0.3, 0.0)
     assert np.array_equal(ids.cpu().numpy(), ids_ref) and np.array_equal(sc.cpu().numpy(), sc_ref)
+
+
+def _random_bf16_cases(n_cases, seed):
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(n_cases):
+        n = int(rs.choice([1, 2, 3, 5, 64, 255, 257, 1001, 3000]))
+        dim = int(rs.choice([8, 9, 40, 100, 128, 256, 300, 512, 768]))   # >= 8: in 1-3 dimensions bf16 rows collide
+                                                                           # exactly and the candidate cut is all ties
+        b = int(rs.randint(1, 10))
+        k = int(rs.randint(1, min(n, 120) + 1))
+        out.append((n, dim, b, k, float(rs.choice([0.0, 0.3, 1.0])), float(rs.choice([0.0, 0.4, -1.0]))))
+    return out
+
+
+@pytest.mark.parametrize("case", _random_bf16_cases(24, seed=4102026), ids=lambda c: "n%d-d%d-b%d-k%d" % c[:4])
+def test_bf16_randomised_shapes_vs_oracle(case):
+    """Seeded sweep over tiny / odd corpora and dimensions for the bf16 small-batch kernels (pair kernel with and
+    without the unpaired last row, 16-byte generic, scalar generic)."""
+    n, dim, b, k, eta, pref = case
+    cb, Eb, dewi32, ent32 = _setup(n, dim, seed=n * 7 + dim)
+    Q = orc.synth_queries(b, dim, seed=dim + b)
+    Qp = np.stack([orc.bf16_round(orc.prepare_query(q)) for q in Q])
+    ids, sc = cb.search(Q, k, eta, pref)
+    assert ids.shape == (b, k) and ids.min() >= 0 and ids.max() < n
+    check_batch(Eb, Qp, dewi32, ent32, k, eta, pref, "cosine", ids, sc, max_excluded_frac=1.0, **TOL)

@@ -303,3 +303,37 @@ def test_ann_semantics_candidates_equal_k():
         assert np.allclose(sc[j], want_sc, atol=1e-5)
     with pytest.raises(ValueError, match="at least k"):
         c.search(Q, k, eta, pref, candidates=k - 1)
+
+
+def _random_cases(n_cases, seed):
+    rs = np.random.RandomState(seed)
+    dims = [1, 3, 7, 8, 24, 33, 64, 96, 100, 128, 129, 200, 256, 384, 512, 640, 768, 1000]
+    out = []
+    for _ in range(n_cases):
+        n = int(rs.choice([1, 2, 3, 17, 64, 255, 256, 257, 1000, 2049, 4000]))
+        dim = int(rs.choice(dims))
+        b = int(rs.randint(1, 10))
+        k = int(rs.randint(1, min(n, 300) + 1))
+        eta = float(rs.choice([0.0, 0.3, 0.5, 1.0, rs.rand()]))
+        pref = float(rs.choice([0.0, -1.0, 0.5, rs.uniform(-1, 1)]))
+        space = str(rs.choice(["cosine", "cosine", "l2"]))
+        out.append((n, dim, b, k, eta, pref, space))
+    return out
+
+
+@pytest.mark.parametrize("case", _random_cases(36, seed=20261004), ids=lambda c: "n%d-d%d-b%d-k%d-%s" % (c[0], c[1], c[2], c[3], c[6]))
+def test_randomised_shapes_vs_oracle(case):
+    """Seeded sweep over corpus size (incl. 1, 2, 3 rows and non-multiples of every tile size), dimension (odd,
+    tiny, non-multiples of 256), batch, k (up to N: candidate count clamps to N), eta / entropy_pref and space."""
+    from dewi import _engine as eng
+    n, dim, b, k, eta, pref, space = case
+    rs = np.random.RandomState(n * 31 + dim)
+    raw = (rs.randn(n, dim) * (0.5 if space == "l2" else 1.0)).astype(np.float32)
+    cols = orc.synth_payload_columns(n, seed=dim)
+    Q = (rs.randn(b, dim) * (0.5 if space == "l2" else 1.0)).astype(np.float32)
+    c = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"], space)
+    E = c.emb.cpu().numpy()
+    dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    ids, sc = c.search(Q, k, eta, pref)
+    assert ids.shape == (b, k) and sc.shape == (b, k) and ids.min() >= 0 and ids.max() < n
+    check_batch(E, Q, dewi32, ent32, k, eta, pref, space, ids, sc, max_excluded_frac=1.0)
