@@ -73,7 +73,10 @@ constexpr int kQB = DEWI_MFMA_QB;
 constexpr int kMfmaThreads = 64 * (8 / kQB);
 constexpr int kTileRows = 32;
 constexpr int kQueriesPerPass = 256;  // 8 waves x 32 (or 4 x 64)
-constexpr int kSampleStride = 32;     // every 32nd tile is a sample tile
+#ifndef DEWI_MFMA_SAMPLE_STRIDE
+#define DEWI_MFMA_SAMPLE_STRIDE 32
+#endif
+constexpr int kSampleStride = DEWI_MFMA_SAMPLE_STRIDE;     // every 32nd tile is a sample tile
 constexpr int kMaxStagedSample = 32 * 1024;  // sample scores per query the threshold kernel keeps in LDS (128 KiB)
 constexpr int kTileBufs = 3;          // LDS ring: the tile being multiplied + two tiles of DMA in flight
 #ifndef DEWI_MFMA_AHEAD
