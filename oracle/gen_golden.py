@@ -263,8 +263,37 @@ def g5():
     print("g5 ok")
 
 
+def g6():
+    """Public API surface of the reference modules on the hot path: class -> public method -> parameters
+    (name, kind, default).  Data only (names and default values), used by tests/test_cpu_host_logic.py to
+    check that the drop-in package accepts every call the reference accepts."""
+    import importlib
+    import inspect
+    surface = {}
+    for modname in ("index", "backends", "scorer", "types"):
+        mod = importlib.import_module("dewi." + modname)
+        for cname, cls in vars(mod).items():
+            if not (inspect.isclass(cls) and cls.__module__ == mod.__name__):
+                continue
+            members = {}
+            for mname, member in vars(cls).items():
+                if mname.startswith("_") and mname != "__init__":
+                    continue
+                fn = member.__func__ if isinstance(member, (classmethod, staticmethod)) else member
+                if not callable(fn):
+                    continue
+                try:
+                    sig = inspect.signature(fn)
+                except (TypeError, ValueError):
+                    continue
+                members[mname] = [[p.name, p.kind.name, None if p.default is inspect.Parameter.empty else repr(p.default)]
+                                  for p in sig.parameters.values()]
+            surface[f"{modname}.{cname}"] = members
+    (OUT / "g6_api_surface.json").write_text(json.dumps(surface, indent=1, sort_keys=True))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
     for name in which:
         globals()[name]()
     for p in sorted(OUT.rglob("*")):

@@ -111,3 +111,33 @@ def test_loading_reference_saved_index_is_host_only(golden_dir):
     di = DewiIndex.load(golden_dir / "g5_dewi_index")
     assert len(di) == 6 and di.get_metadata("id-2") == {"source": "file2.txt"} and di.get_metadata("id-1") is None
     assert np.allclose(np.linalg.norm(di.get_embedding("id-4")), 1.0, atol=1e-6)
+
+
+def test_public_api_accepts_every_reference_call(golden_dir):
+    """g6: every public class / method of the reference's index, backends, scorer and types modules exists here
+    with the same leading parameters (name, kind, default); extra trailing optional parameters are allowed."""
+    import importlib
+    import inspect
+    surface = json.loads((golden_dir / "g6_api_surface.json").read_text())
+    for qual, members in surface.items():
+        modname, cname = qual.split(".")
+        cls = getattr(importlib.import_module("dewi." + modname), cname, None)
+        assert cls is not None, f"missing class {qual}"
+        for mname, ref_params in members.items():
+            assert hasattr(cls, mname), f"missing {qual}.{mname}"
+            member = inspect.getattr_static(cls, mname)
+            fn = member.__func__ if isinstance(member, (classmethod, staticmethod)) else member
+            if not callable(fn):
+                continue
+            try:
+                mine = list(inspect.signature(fn).parameters.values())
+            except (TypeError, ValueError):
+                continue
+            kinds = {p.kind.name for p in mine}
+            for i, (pname, kind, default) in enumerate(ref_params):
+                if kind in ("VAR_POSITIONAL", "VAR_KEYWORD"):
+                    assert kind in kinds, f"{qual}.{mname}: no {kind}"
+                    continue
+                assert i < len(mine) and mine[i].name == pname, f"{qual}.{mname}: parameter {i} should be {pname}"
+                got = None if mine[i].default is inspect.Parameter.empty else repr(mine[i].default)
+                assert got == default, f"{qual}.{mname}({pname}): default {got} != {default}"
