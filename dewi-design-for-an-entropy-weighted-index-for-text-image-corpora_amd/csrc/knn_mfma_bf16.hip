@@ -168,10 +168,10 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
   for (int b = 0; b < kQB; ++b) asm volatile("" ::"v"(thr_l[b]));
 
   // ---- per-lane DMA source offsets (bytes from the tile's first row).  The swizzle repeats every
-  // 16 rows (= KS/2 pieces), so where that is a whole number of this wave's pieces (KS % 16 == 0)
+  // 16 rows (= KS/2 pieces), so where that is a whole number of this wave's pieces (KS % (2 NW) == 0)
   // piece i and piece i + VO differ by the constant 16 * DIM * 2 bytes, which goes into the
-  // instruction's scalar offset: VO = KS/16 registers instead of PPW = KS/8.
-  constexpr int VO = (KS % 16 == 0) ? KS / 16 : PPW;
+  // instruction's scalar offset: VO = KS/(2 NW) registers instead of PPW = KS/NW.
+  constexpr int VO = (KS % (2 * NW) == 0) ? KS / (2 * NW) : PPW;
   uint32_t voff[VO];
 #pragma unroll
   for (int i = 0; i < VO; ++i) {
@@ -235,6 +235,12 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
 #pragma unroll
     for (int i = 0; i < PPW; ++i) issue_piece(rs, 1, i);
   }
+  // the survivor stores take their base address from an SGPR pair: make the pointer provably wave-uniform
+  // (with 512 registers per wave hipcc otherwise hands the inline asm a VGPR pair for the "s" operand)
+  const uint64_t out_bits = reinterpret_cast<uint64_t>(out);
+  uint64_t* const out_uniform = reinterpret_cast<uint64_t*>(
+      (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(out_bits >> 32)))) << 32) |
+      static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(out_bits))));
   // The epilogue of tile i: D[doc = (j&3) + 8*(j>>2) + 4*h][query = 32*wave + r].
   auto epilogue = [&](f32x16 (&acc)[kQB], int64_t i) {
     const int64_t row0 = i * tile_stride * kTileRows;
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
                 "v_add_u32 %[off], 8, %[off]\n\t"
                 "s_mov_b64 exec, %[sv]"
                 : [off] "+v"(off[b]), [sv] "=&s"(saved_exec)
-                : [f] "v"(flag), [rec] "v"(rec), [base] "s"(out)
+                : [f] "v"(flag), [rec] "v"(rec), [base] "s"(out_uniform)
                 : "vcc", "memory");
           };
           // Three vector instructions per register: the compare, a select for the score, and an
@@ -340,7 +346,7 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
   // filter it; waves NW/2.. filter tile i-1 FIRST and multiply tile i afterwards.  One wave of each
   // SIMD is therefore in its matrix block while the other is in its (matrix-pipe-idle) epilogue,
   // instead of both competing for the pipe and then both leaving it idle.
-  const bool deferred = wave_u >= NW / 2;
+  const bool deferred = kQB == 1 && wave_u >= NW / 2;   // one wave per SIMD (kQB = 2): nothing to stagger against
 #ifdef DEWI_MFMA_STAMPS
   uint64_t st_dma = 0, st_vm = 0, st_wait = 0, st_mfma = 0, st_epi = 0, st_t0 = __builtin_readcyclecounter(), st_tiles = 0;
 #define ST_NOW() __builtin_readcyclecounter()
