@@ -65,9 +65,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4m __attribute__((ext_vector_type(4)));
 
 #ifndef DEWI_MFMA_QB
-#define DEWI_MFMA_QB 1   // 32-query blocks per wave: 1 -> 8 waves (two per SIMD, 256 registers each), 2 -> 4 waves.
-                         // Measured (1M x 768, 256 queries): 8 waves 379 us, 4 waves 492 us per pass — with one wave
-                         // per SIMD nothing covers its DMA issue, epilogue and barrier time.
+#define DEWI_MFMA_QB 1   // 32-query blocks per wave: 1 -> 8 waves (two per SIMD, 256 registers each), 2 -> 4 waves
+                         // (one per SIMD, 492 of 512 registers at dim 768, no spills).  Measured (1M x 768, 256 queries):
+                         // 8 waves 345 us; 4 waves with both chains interleaved per k-step and the side phase after
+                         // the block 357 us; 4 waves with block 0's and block 1's chains one after the other (A
+                         // fragments read twice) so that each block is filtered during the other's chain: 425-435 us,
+                         // wherever the filter's instructions and the DMA pieces were placed and however deep the
+                         // fragment prefetch.
 #endif
 constexpr int kQB = DEWI_MFMA_QB;
 constexpr int kMfmaThreads = 64 * (8 / kQB);
