@@ -4,7 +4,7 @@ sys.path.insert(0, "dewi-design-for-an-entropy-weighted-index-for-text-image-cor
 from dewi import _engine as eng
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(42)
-n, d = 1_000_000, 768
+n, d = (int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000), 768
 emb = torch.randn((n, d), generator=g, device=dev); emb /= emb.norm(dim=1, keepdim=True)
 c = eng.DeviceCorpus(emb, torch.rand(n, device=dev), torch.rand(n, device=dev), "cosine")
 Q = np.random.RandomState(1).randn(300, d).astype(np.float32)
