@@ -4,6 +4,7 @@
 // functions validate arguments, carve the caller's workspace, choose launch shapes and enqueue
 // kernels; no allocation, no device synchronisation (except dewi_timing_read).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -145,7 +146,10 @@ int run_scan(const KnnLayout& L, const void* d_E, int elem_type, int64_t n_rows,
   ScanTimer timer(stream);
   int q = 0;
   while (q < n_queries) {
-    const int nq = (n_queries - q >= 4) ? 4 : 1;
+    // queries per corpus pass: 8 (fp32 row-per-wave kernel with one sorted list per workgroup), else 4, else 1
+    static const bool nq8_enabled = [] { const char* e = getenv("DEWI_SCAN_NQ8"); return e == nullptr || atoi(e) != 0; }();
+    const bool can8 = !elem_type && L.plan.fast && L.plan.slots == 1 && nq8_enabled;
+    const int nq = (can8 && n_queries - q >= 8) ? 8 : ((n_queries - q >= 4) ? 4 : 1);
     if (elem_type)
       e = dewi::launch_scan_bf16(L.plan, static_cast<const uint16_t*>(d_E), n_rows, dim, d_Q, L.plan.fast ? nullptr : qn,
                                  q, nq, n_candidates, space, keys, stream);

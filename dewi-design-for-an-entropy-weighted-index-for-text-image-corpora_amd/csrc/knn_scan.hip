@@ -296,7 +296,10 @@ ScanPlan plan_scan(int64_t n_rows, int dim, int elem_bytes, int n_candidates, in
     p.fast = (dim % 256 == 0) && (u == 1 || u == 2 || u == 3 || u == 4 || u == 6);
     p.vec = (dim % 4 == 0) ? 4 : 1;
     p.rows_per_iter = u == 1 ? 4 : (u == 2 ? 2 : 1);  // ~3-4 KiB in flight per wave
-    if (p.fast && tuning.rows_per_iter > 0) p.rows_per_iter = tuning.rows_per_iter;
+    // four queries per corpus pass quadruple the arithmetic behind every row: two rows in flight per wave
+    // (1 M x 768, batch 4: R=1 0.562 ms, R=2 0.468, R=4 0.468)
+    p.rows_per_iter_batch = p.rows_per_iter < 2 ? 2 : p.rows_per_iter;
+    if (p.fast && tuning.rows_per_iter > 0) p.rows_per_iter = p.rows_per_iter_batch = tuning.rows_per_iter;
   }
   const int units = (dim + p.vec - 1) / p.vec;
   p.group = p.fast ? kWave : (next_pow2(units) > kWave ? kWave : next_pow2(units));
@@ -338,7 +341,7 @@ static bool launch_fast_r(const ScanPlan& plan, const float* E, int64_t n_rows, 
                           uint64_t* keys, hipStream_t stream) {
   // R only changes how rows are grouped per wave; results do not depend on it.  Combinations that
   // are not instantiated (register budget, build time) step down to the next smaller R.
-  const int r = plan.rows_per_iter;
+  const int r = NQ >= 4 ? plan.rows_per_iter_batch : plan.rows_per_iter;
   if (r >= 8) {
     if constexpr (U <= 3 && NQ == 1 && S == 1) {
       launch_fast_nt<U, 8, NQ, SPACE, S>(plan, E, n_rows, Q, c, keys, stream);
@@ -418,6 +421,10 @@ hipError_t launch_scan_f32(const ScanPlan& plan, const float* d_E, int64_t n_row
     DEWI_DISPATCH(1)
   } else if (nq == 4) {
     DEWI_DISPATCH(4)
+  } else if (nq == 8 && plan.fast && plan.slots == 1) {   // eight queries per corpus pass: row-per-wave kernel, c <= 64 only
+    if (space == DEWI_SPACE_COSINE)
+      return launch_scan_impl<8, DEWI_SPACE_COSINE, 1>(plan, d_E, n_rows, dim, qr, qn, n_candidates, keys, stream);
+    return launch_scan_impl<8, DEWI_SPACE_L2, 1>(plan, d_E, n_rows, dim, qr, qn, n_candidates, keys, stream);
   }
 #undef DEWI_DISPATCH
 #undef DEWI_DISPATCH_S

@@ -23,6 +23,7 @@ struct ScanPlan {
   int blocks;         // workgroups of kScanThreads
   int waves;          // blocks * (kScanThreads / 64)
   int rows_per_iter;  // rows each wave loads before it reduces (fast path)
+  int rows_per_iter_batch;  // the same for passes that serve four queries at once
   bool fast;          // dim == 256*U (fp32: U in 1,2,3,4,6; bf16: 1..4): row-per-wave / row-pair-per-wave kernel
   bool dense;         // one key per row instead of per-wave lists
   int slots;          // key registers per lane per query: 1 (c <= 64), 4 (c <= 256), 0 (dense)

@@ -53,6 +53,10 @@ out["bf16_b1_k10"] = {"ms_per_query": round(t1 * 1e3, 4), "queries_per_s": round
                       "hbm_GBps": round(n * d * 2 / t1 / 1e9, 1)}
 t4 = timed(lambda: c32.search_device(Q[next(it) % 8][:4].contiguous(), 10, 0.3, 0.0), reps=100)
 out["f32_b4_k10"] = {"ms_per_batch": round(t4 * 1e3, 4), "queries_per_s": round(4 / t4, 1)}
+Q8 = torch.randn((8, 8, d), generator=g, device=dev)
+t8 = timed(lambda: c32.search_device(Q8[next(it) % 8], 10, 0.3, 0.0), reps=100)
+out["f32_b8_k10"] = {"ms_per_batch": round(t8 * 1e3, 4), "queries_per_s": round(8 / t8, 1)}
+del Q8
 del cb, c32, emb, Q
 torch.cuda.empty_cache()
 

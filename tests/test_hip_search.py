@@ -337,3 +337,25 @@ def test_randomised_shapes_vs_oracle(case):
     ids, sc = c.search(Q, k, eta, pref)
     assert ids.shape == (b, k) and sc.shape == (b, k) and ids.min() >= 0 and ids.max() < n
     check_batch(E, Q, dewi32, ent32, k, eta, pref, space, ids, sc, max_excluded_frac=1.0)
+
+
+@pytest.mark.parametrize("space", ["cosine", "l2"])
+@pytest.mark.parametrize("dim", [256, 768, 1536])
+def test_eight_queries_per_pass(dim, space):
+    """21 queries = 8 + 8 + 4 + 1: every queries-per-pass variant of the row-per-wave fp32 kernel in one call; the
+    answers must not depend on how the batch is cut (same rows, same order of every per-row sum)."""
+    from dewi import _engine as eng
+    n = 3001
+    rs = np.random.RandomState(dim)
+    scale = 0.5 if space == "l2" else 1.0
+    raw = (rs.randn(n, dim) * scale).astype(np.float32)
+    cols = orc.synth_payload_columns(n, seed=dim)
+    Q = (rs.randn(21, dim) * scale).astype(np.float32)
+    c = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"], space)
+    ids, sc = c.search(Q, 10, 0.3, 0.1)
+    for j in (0, 7, 8, 15, 16, 19, 20):                        # one at a time: the single-query kernel
+        i1, s1 = c.search(Q[j], 10, 0.3, 0.1)
+        assert np.array_equal(i1[0], ids[j]) and np.array_equal(s1[0], sc[j]), j
+    E = c.emb.cpu().numpy()
+    dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    check_batch(E, Q, dewi32, ent32, 10, 0.3, 0.1, space, ids, sc, max_excluded_frac=0.4)
