@@ -590,7 +590,7 @@ __global__ __launch_bounds__(kSelectThreads) void sample_threshold_kernel(const 
 // host side
 // ---------------------------------------------------------------------------------------------
 bool mfma_path_supported(int64_t n_rows, int dim, int n_queries, int n_candidates, int space) {
-  return space == DEWI_SPACE_COSINE && n_queries >= 16 && dim % 128 == 0 && dim <= 768 &&
+  return space == DEWI_SPACE_COSINE && n_queries >= kMfmaMinQueries && dim % 128 == 0 && dim <= 768 &&
          n_rows >= 64 * 1024 && n_candidates <= kMaxSortCandidates &&
          n_rows / (kTileRows * kSampleStride) * kTileRows >= 4 * static_cast<int64_t>(n_candidates);
 }
