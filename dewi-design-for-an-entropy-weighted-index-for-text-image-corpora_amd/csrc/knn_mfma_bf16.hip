@@ -130,7 +130,7 @@ template <int KS, bool DENSE>
 __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
     const uint16_t* __restrict__ E, int64_t n_rows, const uint16_t* __restrict__ Qb, int64_t n_tiles,
     int64_t tile_stride, const float* __restrict__ thr, uint64_t* __restrict__ out, int64_t out_stride,
-    uint32_t* __restrict__ cnt) {
+    uint32_t* __restrict__ cnt, int n_active) {
   // DENSE: `out` is a float array: out[q * out_stride + sample position] = score of every document of the
   //        (strided) tiles.
   // filter: raw records out[((2*blockIdx.x + h) * 256 + q) * out_stride + slot], cnt[(2*blockIdx.x + h) * 256 + q].
@@ -150,16 +150,24 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
 
   // ---- query fragments (B operand): two 32-query blocks per wave; lane holds
   //      Qb[64*wave + 32*b + r][16 s + 8 h .. +7]
+  // n_active = real queries in this group of 256; the rest is zero padding.  A padding query scores 0
+  // against every document and its sample threshold is 0 too, so it would "pass" everywhere and bury the
+  // epilogue in stores: its threshold is forced to +inf below.  A wave none of whose queries is real skips
+  // the matrix block and the filter altogether; it still moves its share of every tile and meets the
+  // barrier.
+  const bool active = 32 * kQB * __builtin_amdgcn_readfirstlane(wave) < n_active;
   bf16x8 qf[kQB][KS];
 #pragma unroll
   for (int b = 0; b < kQB; ++b) {
     const bf16x8* qp = reinterpret_cast<const bf16x8*>(Qb + static_cast<int64_t>(32 * kQB * wave + 32 * b + r) * DIM + 8 * h);
 #pragma unroll
-    for (int s = 0; s < KS; ++s) qf[b][s] = qp[2 * s];
+    for (int s = 0; s < KS; ++s) qf[b][s] = qp[active ? 2 * s : 0];
   }
   float thr_l[kQB];
 #pragma unroll
-  for (int b = 0; b < kQB; ++b) thr_l[b] = DENSE ? -__builtin_inff() : thr[32 * kQB * wave + 32 * b + r];
+  for (int b = 0; b < kQB; ++b)
+    thr_l[b] = DENSE ? -__builtin_inff()
+                     : (32 * kQB * wave + 32 * b + r < n_active ? thr[32 * kQB * wave + 32 * b + r] : __builtin_inff());
   // Pin the compiler's waits for these loads HERE, before any DMA is in flight: their first real use
   // is inside the tile loop, and a compiler-inserted vmcnt(0) there would drain the prefetch of the
   // next tile on every iteration.
@@ -392,7 +400,7 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
       asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(a_addr[s & 7]), "n"(256 * (s >> 3)));
     };
 #pragma unroll
-    for (int s = 0; s < kAhead; ++s) read_fragment(ring[s], s);
+    for (int s = 0; s < kAhead && active; ++s) read_fragment(ring[s], s);
 
     // The half of a period a wave does NOT spend in its matrix block: wait for its pieces of the next
     // tile, send the pieces of tile i+2, filter a finished tile.  The DMA is issued here and not between
@@ -420,7 +428,7 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
       st_vm += sp1 - sp0;
       st_dma += sp2 - sp1;
 #endif
-      if (filter) epilogue(acc, filter_tile);
+      if (filter && active) epilogue(acc, filter_tile);
     };
 
 #ifdef DEWI_MFMA_STAMPS
@@ -430,6 +438,7 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
 #ifdef DEWI_MFMA_STAMPS
     const uint64_t st_c = ST_NOW();
 #endif
+    if (active) {
     if (DEWI_MFMA_PRIO) __builtin_amdgcn_s_setprio(3);   // the matrix block wins issue arbitration against the other wave's epilogue
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -450,6 +459,7 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
     }
 
     if (DEWI_MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
+    }
 #ifdef DEWI_MFMA_STAMPS
     asm volatile("" ::"v"(acc[0]));
     const uint64_t st_w = ST_NOW();
@@ -468,7 +478,7 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
     for (int j = 0; j < 8; ++j) a_addr[j] = buf == kTileBufs - 1 ? a_addr[j] - (kTileBufs - 1) * TILE_BYTES : a_addr[j] + TILE_BYTES;
     buf = buf == kTileBufs - 1 ? 0 : buf + 1;
   }
-  if (deferred && prev >= 0) epilogue(acc, prev);
+  if (deferred && prev >= 0 && active) epilogue(acc, prev);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef DEWI_MFMA_STAMPS
   if (!DENSE && blockIdx.x == 3 && lane == 0)
@@ -621,8 +631,8 @@ MfmaLayout plan_mfma(int64_t n_rows, int dim, int n_queries, int n_candidates, i
 }
 
 template <int KS>
-static hipError_t run_mfma_dim(const MfmaLayout& m, const uint16_t* E, int64_t n_rows, int n_candidates, char* ws,
-                               int compute_units, hipStream_t stream) {
+static hipError_t run_mfma_dim(const MfmaLayout& m, const uint16_t* E, int64_t n_rows, int n_queries, int n_candidates,
+                               char* ws, int compute_units, hipStream_t stream) {
   constexpr int DIM = KS * 16;
   const int lds_bytes = kTileBufs * kTileRows * DIM * 2;
   static bool attr_done = false;
@@ -648,23 +658,25 @@ static hipError_t run_mfma_dim(const MfmaLayout& m, const uint16_t* E, int64_t n
     float* tg = thr + g * kQueriesPerPass;
     uint32_t* cg = cnt + static_cast<int64_t>(g) * m.n_seg * kQueriesPerPass;
     uint64_t* og = cand + static_cast<int64_t>(g) * m.n_seg * kQueriesPerPass * m.seg_cap;
+    const int n_active = n_queries - g * kQueriesPerPass < kQueriesPerPass ? n_queries - g * kQueriesPerPass : kQueriesPerPass;
     // 1. dense scores of the strided sample
     const int sample_blocks = m.n_sample_tiles < compute_units ? static_cast<int>(m.n_sample_tiles) : compute_units;
     hipLaunchKernelGGL((mfma_scan_bf16<KS, true>), dim3(sample_blocks), dim3(kMfmaThreads), lds_bytes, stream, E, n_rows,
                        qg, m.n_sample_tiles, static_cast<int64_t>(kSampleStride), static_cast<const float*>(nullptr),
-                       reinterpret_cast<uint64_t*>(dense), m.sample_stride, static_cast<uint32_t*>(nullptr));
-    // 2. per-query threshold
+                       reinterpret_cast<uint64_t*>(dense), m.sample_stride, static_cast<uint32_t*>(nullptr), n_active);
+    // 2. per-query threshold (real queries only: a padding query's sample scores are all equal, which is the
+    //    worst case of the histogram select, and its threshold is not used)
     if (m.sample_stride <= kMaxStagedSample)
-      hipLaunchKernelGGL(sample_threshold_kernel<true>, dim3(kQueriesPerPass), dim3(kSelectThreads),
+      hipLaunchKernelGGL(sample_threshold_kernel<true>, dim3(n_active), dim3(kSelectThreads),
                          static_cast<size_t>(m.sample_stride) * 4, stream, dense, m.sample_stride, m.sample_stride,
                          n_candidates, tg);
     else
-      hipLaunchKernelGGL(sample_threshold_kernel<false>, dim3(kQueriesPerPass), dim3(kSelectThreads), 0, stream, dense,
+      hipLaunchKernelGGL(sample_threshold_kernel<false>, dim3(n_active), dim3(kSelectThreads), 0, stream, dense,
                          m.sample_stride, m.sample_stride, n_candidates, tg);
     // 3. full pass with the filter: n_blocks workgroups, each writing its own half-segments and counts
     hipLaunchKernelGGL((mfma_scan_bf16<KS, false>), dim3(m.n_blocks), dim3(kMfmaThreads), lds_bytes, stream, E, n_rows, qg,
                        m.n_tiles, static_cast<int64_t>(1), static_cast<const float*>(tg), og,
-                       static_cast<int64_t>(m.seg_cap), cg);
+                       static_cast<int64_t>(m.seg_cap), cg, n_active);
   }
   return hipGetLastError();
 }
@@ -675,12 +687,12 @@ hipError_t launch_mfma_bf16(const MfmaLayout& m, const uint16_t* d_E, int64_t n_
   hipLaunchKernelGGL(prepare_queries_bf16, dim3(m.q_pad), dim3(kWave), 0, stream, d_Q,
                      reinterpret_cast<uint16_t*>(ws + m.qb_off), n_queries, dim, space);
   switch (dim / 16) {
-    case 8: return run_mfma_dim<8>(m, d_E, n_rows, n_candidates, ws, compute_units, stream);
-    case 16: return run_mfma_dim<16>(m, d_E, n_rows, n_candidates, ws, compute_units, stream);
-    case 24: return run_mfma_dim<24>(m, d_E, n_rows, n_candidates, ws, compute_units, stream);
-    case 32: return run_mfma_dim<32>(m, d_E, n_rows, n_candidates, ws, compute_units, stream);
-    case 40: return run_mfma_dim<40>(m, d_E, n_rows, n_candidates, ws, compute_units, stream);
-    case 48: return run_mfma_dim<48>(m, d_E, n_rows, n_candidates, ws, compute_units, stream);
+    case 8: return run_mfma_dim<8>(m, d_E, n_rows, n_queries, n_candidates, ws, compute_units, stream);
+    case 16: return run_mfma_dim<16>(m, d_E, n_rows, n_queries, n_candidates, ws, compute_units, stream);
+    case 24: return run_mfma_dim<24>(m, d_E, n_rows, n_queries, n_candidates, ws, compute_units, stream);
+    case 32: return run_mfma_dim<32>(m, d_E, n_rows, n_queries, n_candidates, ws, compute_units, stream);
+    case 40: return run_mfma_dim<40>(m, d_E, n_rows, n_queries, n_candidates, ws, compute_units, stream);
+    case 48: return run_mfma_dim<48>(m, d_E, n_rows, n_queries, n_candidates, ws, compute_units, stream);
     default: return hipErrorInvalidValue;
   }
 }
