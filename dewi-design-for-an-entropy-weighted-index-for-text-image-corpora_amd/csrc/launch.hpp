@@ -10,8 +10,8 @@ namespace dewi {
 
 // Per-wave candidate lists hold at most kMaxListCandidates keys (4 register slots x 64 lanes);
 // larger candidate counts take the dense path (one key per row, selected afterwards).
-constexpr int kMfmaMinQueries = 5;     // bf16 corpus: batches of at least this many queries take the matrix-core path
-                                       // (1 M x 768: 4 queries 0.36 ms in one small-batch pass, 5 need a second one = 0.58 ms; batched: 0.43 ms)
+constexpr int kMfmaMinQueries = 2;     // bf16 corpus: batches of at least this many queries take the matrix-core path
+                                       // (1 M x 768, k = 10: 2 / 3 / 4 queries 0.45 / 0.68 / 0.35 ms on the small-batch kernels, 0.32 ms batched)
 constexpr int kMaxListCandidates = 256;
 // The select / re-rank kernel sorts its candidates in LDS.
 constexpr int kMaxSortCandidates = 2048;

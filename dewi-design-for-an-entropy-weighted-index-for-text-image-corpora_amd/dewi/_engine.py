@@ -210,8 +210,8 @@ class DeviceCorpus:
             # id -1: such queries are answered again by the exact small-batch kernels.
             if ids_h.size and (ids_h[:, 0] < 0).any():
                 redo = np.nonzero(ids_h[:, 0] < 0)[0]
-                for s0 in range(0, len(redo), 4):            # batches of 4 stay on the exact small-batch kernels
-                    sel = redo[s0:s0 + 4]
+                for s0 in range(0, len(redo)):               # one at a time: the exact small-batch kernels
+                    sel = redo[s0:s0 + 1]
                     sub = q[torch.from_numpy(sel).to(q.device)].contiguous()
                     i2, s2 = self.search_device(sub, k, eta, entropy_pref, candidates=candidates)
                     ids_h[sel] = i2.cpu().numpy()

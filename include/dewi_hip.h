@@ -148,10 +148,10 @@ int dewi_knn_rerank_bf16(const uint16_t* d_E, int64_t n_rows, int dim, const flo
  * shard's best `n_candidates` rows per query as dewi_candidate records sorted by (sim desc, id
  * asc); records past min(n_candidates, n_rows) are padding (id = -1, sim = -inf).
  * `id_offset` is added to the local row index.  d_out [n_queries][n_candidates].
- * elem_type: 0 = fp32 corpus, 1 = bf16 corpus.  A bf16 shard with >= 5 queries takes the batched
+ * elem_type: 0 = fp32 corpus, 1 = bf16 corpus.  A bf16 shard with >= 2 queries takes the batched
  * matrix-core path (same conditions as dewi_knn_rerank_bf16); a query whose survivor buffer
  * overflowed there is NOT answered and all its records carry id = -2 (sim NaN): dewi_merge_rerank
- * then returns id -1 for that query and the caller re-runs it in batches of < 5 queries.
+ * then returns id -1 for that query and the caller re-runs it alone (a single query always takes the exact small-batch kernels).
  * ------------------------------------------------------------------------------------------ */
 int dewi_knn_candidates(const void* d_E, int elem_type, int64_t n_rows, int dim, const float* d_Q,
                         int n_queries, const float* d_dewi32, const float* d_ent32, int n_candidates,

@@ -74,10 +74,16 @@ def test_c3_bf16_batched_properties(corpus_1m):
     assert all(len(set(r.tolist())) == k for r in ids[:16])
     ids2, sc2 = cb.search_device(Qb, k, eta, 0.0)                               # deterministic despite the
     assert torch.equal(ids2, ids) and torch.equal(sc2, sc)                      # order survivors are stored in
-    # agreement with the exact small-batch bf16 kernels (batches of 4 stay off the matrix-core path;
-    # different summation order)
+    # agreement with the exact small-batch bf16 kernels (matrix-core path switched off; different summation
+    # order)
+    from dewi import _engine as eng
     for q0 in (0, 4):
-        ids_s, sc_s = cb.search_device(Qb[q0:q0 + 4].contiguous(), k, eta, 0.0)
+        eng.tuning(0, 0, -1, 0)
+        try:
+            ids_s, sc_s = cb.search_device(Qb[q0:q0 + 4].contiguous(), k, eta, 0.0)
+            torch.cuda.synchronize()
+        finally:
+            eng.tuning(0, 0, -1, 1)
         assert (ids_s == ids[q0:q0 + 4]).float().mean().item() > 0.97
         assert torch.allclose(torch.sort(sc_s, dim=1).values, torch.sort(sc[q0:q0 + 4], dim=1).values, atol=2e-5)
     # ... and a batch of 8 takes the matrix-core path too: same answers as inside the batch of 256

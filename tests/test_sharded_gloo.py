@@ -182,7 +182,7 @@ def test_two_ranks_on_one_gpu_equal_single_device():
 
 
 # ---- GPU: bf16 shards with a query batch large enough for the matrix-core path ---------------------
-_BF16 = dict(n=140_000, d=128, b=40, k=10)          # 70 K rows per shard (>= 64 K), 40 queries (>= 5)
+_BF16 = dict(n=140_000, d=128, b=40, k=10)          # 70 K rows per shard (>= 64 K), 40 queries (>= 2)
 
 
 def _bf16_inputs(duplicates):
