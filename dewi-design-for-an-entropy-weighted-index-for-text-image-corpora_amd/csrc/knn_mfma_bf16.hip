@@ -18,7 +18,9 @@
 // is zero-sum (MI355X_MICROARCH.md, "Two waves per SIMD").  In-kernel stamps, cycles per tile and
 // wave: matrix block 1.6-1.8 K (48 MFMAs x 32 = 1536 ideal), side phase 1.7-1.9 K (DMA issue 0.35-
 // 0.45 K, wait for own pieces 0.15 K, filter ~1.1 K), barrier 0.7-1.1 K.  Ablations: no DMA after
-// the first tile 292 us, no filter 305 us.  Two 32-query blocks per A fragment (half the LDS reads,
+// the first tile 292 us, no filter 305 us.  Tile delivery is the other ceiling: with 8 queries (one
+// matrix wave per workgroup, seven waves only moving tiles) a pass still takes 264 us = 5.8 TB/s, the
+// LDS-DMA fill rate; 128 queries 294 us, 256 queries 345 us.  Two 32-query blocks per A fragment (half the LDS reads,
 // half the waves) need 384 query registers per wave at dim 768: 4 waves x 512 registers measured
 // 492 us (no partner wave to cover the side phase).
 //
