@@ -88,6 +88,10 @@ constexpr int kTileBufs = 3;          // LDS ring: the tile being multiplied + t
 #ifndef DEWI_MFMA_AHEAD
 #define DEWI_MFMA_AHEAD 3   // A fragments in flight ahead of the MFMA being fed (4 VGPRs each; 2..10 measured equal)
 #endif
+#ifndef DEWI_MFMA_DMA_AUX
+#define DEWI_MFMA_DMA_AUX 2   // cache policy bits of the tile DMA (gfx940+: 1 = sc0, 2 = nt, 16 = sc1).  The corpus is read once:
+                               // non-temporal 334 us per pass at 256 queries and 240 us at 8, default policy 355 and 264
+#endif
 #ifndef DEWI_MFMA_PRIO
 #define DEWI_MFMA_PRIO 1
 #endif
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
   };
   auto issue_piece = [&](__amdgpu_buffer_rsrc_t rsrc, int buf, int i) {
     char* l = lds + buf * TILE_BYTES + (i * NW + wave_u) * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)(l), 16, voff[i % VO], (i / VO) * (16 * DIM * 2), 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)(l), 16, voff[i % VO], (i / VO) * (16 * DIM * 2), 0, DEWI_MFMA_DMA_AUX);
   };
 
   // ---- survivor segments.  Queries belong to exactly one wave and to exactly two of its lanes
