@@ -36,29 +36,36 @@ struct DeviceInfo {
   int wave = 0;
   size_t mem = 0;
 };
-DeviceInfo g_dev;
+// Facts of the CALLING THREAD's current device, cached per device ordinal (a process may drive
+// several GPUs from several threads).
+constexpr int kMaxDevices = 64;
+DeviceInfo g_dev[kMaxDevices];
 std::mutex g_dev_mu;
 
 int ensure_device(DeviceInfo& out) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
+  if (dev < 0 || dev >= kMaxDevices) return fail(DEWI_ERR_UNSUPPORTED, "device ordinal %d out of range", dev);
   std::lock_guard<std::mutex> lk(g_dev_mu);
-  if (!g_dev.ready) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
+  DeviceInfo& d = g_dev[dev];
+  if (!d.ready) {
     hipDeviceProp_t p;
     e = hipGetDeviceProperties(&p, dev);
     if (e != hipSuccess) return hip_fail(e, "hipGetDeviceProperties");
-    g_dev.cus = p.multiProcessorCount;
-    g_dev.wave = p.warpSize;
-    g_dev.mem = p.totalGlobalMem;
-    if (g_dev.wave != 64) return fail(DEWI_ERR_UNSUPPORTED, "wavefront size %d: this library is written for gfx950 (wave64)", g_dev.wave);
-    g_dev.ready = true;
+    d.cus = p.multiProcessorCount;
+    d.wave = p.warpSize;
+    d.mem = p.totalGlobalMem;
+    if (d.wave != 64) return fail(DEWI_ERR_UNSUPPORTED, "wavefront size %d: this library is written for gfx950 (wave64)", d.wave);
+    d.ready = true;
   }
-  out = g_dev;
+  out = d;
   return DEWI_OK;
 }
 
-dewi::Tuning g_tuning{0, 0, -1, 1};
+// Launch-shape overrides belong to the calling thread (dewi_tuning_set): a sweep or a test in one
+// thread cannot change the plan — and with it the workspace layout — under another thread's calls.
+thread_local dewi::Tuning g_tuning{0, 0, -1, 1};
 
 // ---- timing ring -----------------------------------------------------------------------------
 struct Timing {
@@ -69,26 +76,40 @@ struct Timing {
 } g_timing;
 std::mutex g_timing_mu;
 
+// One bracket = two events around the dominant corpus-pass kernel of a call.  begin() decides whether this
+// call is sampled; end() records the stop event of the bracket begin() opened on this thread.
+thread_local hipEvent_t t_open_stop = nullptr;
+
+}  // namespace
+
+namespace dewi {
+void timing_begin(hipStream_t stream) {
+  std::lock_guard<std::mutex> lk(g_timing_mu);
+  t_open_stop = nullptr;
+  if (g_timing.every <= 0) return;
+  if ((g_timing.calls++ % static_cast<unsigned long>(g_timing.every)) != 0) return;
+  if (g_timing.used == g_timing.start.size()) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    g_timing.start.push_back(a);
+    g_timing.stop.push_back(b);
+  }
+  (void)hipEventRecord(g_timing.start[g_timing.used], stream);
+  t_open_stop = g_timing.stop[g_timing.used];
+  ++g_timing.used;
+}
+void timing_end(hipStream_t stream) {
+  if (t_open_stop) (void)hipEventRecord(t_open_stop, stream);
+  t_open_stop = nullptr;
+}
+}  // namespace dewi
+
+namespace {
+
 struct ScanTimer {
   hipStream_t stream;
-  hipEvent_t stop = nullptr;
-  explicit ScanTimer(hipStream_t s) : stream(s) {
-    std::lock_guard<std::mutex> lk(g_timing_mu);
-    if (g_timing.every <= 0) return;
-    if ((g_timing.calls++ % static_cast<unsigned long>(g_timing.every)) != 0) return;
-    if (g_timing.used == g_timing.start.size()) {
-      hipEvent_t a, b;
-      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
-      g_timing.start.push_back(a);
-      g_timing.stop.push_back(b);
-    }
-    (void)hipEventRecord(g_timing.start[g_timing.used], stream);
-    stop = g_timing.stop[g_timing.used];
-    ++g_timing.used;
-  }
-  ~ScanTimer() {
-    if (stop) (void)hipEventRecord(stop, stream);
-  }
+  explicit ScanTimer(hipStream_t s) : stream(s) { dewi::timing_begin(s); }
+  ~ScanTimer() { dewi::timing_end(stream); }
 };
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -122,8 +143,10 @@ KnnLayout layout_knn(int64_t n_rows, int dim, int elem_bytes, int n_queries, int
   return L;
 }
 
-dewi::RerankParams make_rerank(double eta, double pref) {
+dewi::RerankParams make_rerank(double eta, double pref, int transform = DEWI_SIM_RAW, int space = DEWI_SPACE_COSINE) {
   dewi::RerankParams rp;
+  rp.transform = transform;
+  rp.space = space;
   // NumPy treats the Python floats (1 - eta), eta, entropy_pref as weak scalars: each is rounded to
   // fp32 once and the array arithmetic stays fp32 (reference backends.py:461-465).
   rp.w_sim = static_cast<float>(1.0 - eta);
@@ -176,7 +199,7 @@ int check_common(const void* d_E, int64_t n_rows, int dim, const float* d_Q, int
 int knn_rerank_impl(const void* d_E, int elem_type, int64_t n_rows, int dim, const float* d_Q, int n_queries,
                     const float* d_dewi32, const float* d_ent32, int k, double eta, double pref, int space,
                     int64_t* d_out_ids, float* d_out_scores, void* d_ws, size_t ws_bytes, void* stream_,
-                    int n_candidates_override = 0) {
+                    int n_candidates_override = 0, int transform = DEWI_SIM_RAW) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   int rc = check_common(d_E, n_rows, dim, d_Q, n_queries, space);
   if (rc) return rc;
@@ -201,15 +224,11 @@ int knn_rerank_impl(const void* d_E, int elem_type, int64_t n_rows, int dim, con
     // many queries over a bf16 corpus: matrix-core path, one corpus pass per 256 queries
     const dewi::MfmaLayout M = dewi::plan_mfma(n_rows, dim, n_queries, c, dev.cus);
     if (!d_ws || ws_bytes < M.total) return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, M.total);
-    hipError_t e;
-    {
-      ScanTimer timer(stream);
-      e = dewi::launch_mfma_bf16(M, static_cast<const uint16_t*>(d_E), n_rows, dim, d_Q, n_queries, c, space, ws, dev.cus,
-                                 stream);
-    }
+    hipError_t e = dewi::launch_mfma_bf16(M, static_cast<const uint16_t*>(d_E), n_rows, dim, d_Q, n_queries, c, space, ws,
+                                          dev.cus, stream);   // brackets its filter pass for dewi_timing_read itself
     if (e != hipSuccess) return hip_fail(e, "mfma scan launch");
     // one select launch per group of 256 queries (each group has its own segments)
-    const dewi::RerankParams rp = make_rerank(eta, pref);
+    const dewi::RerankParams rp = make_rerank(eta, pref, transform, space);
     for (int g = 0; g < M.groups; ++g) {
       const int q0 = g * 256;
       const int nq = n_queries - q0 < 256 ? n_queries - q0 : 256;
@@ -229,7 +248,7 @@ int knn_rerank_impl(const void* d_E, int elem_type, int64_t n_rows, int dim, con
   if (!d_ws || ws_bytes < L.total) return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, L.total);
   rc = run_scan(L, d_E, elem_type, n_rows, dim, d_Q, n_queries, c, space, ws, stream);
   if (rc) return rc;
-  const dewi::RerankParams rp = make_rerank(eta, pref);
+  const dewi::RerankParams rp = make_rerank(eta, pref, transform, space);
   if (c > dewi::kMaxSortCandidates) {  // k > 1024: candidate arrays live in global memory
     uint64_t* g1 = reinterpret_cast<uint64_t*>(ws + L.big_off);
     hipError_t e2 = dewi::launch_select_rerank_large(reinterpret_cast<const uint64_t*>(ws + L.keys_off),
@@ -321,11 +340,21 @@ int dewi_knn_rerank_f32(const float* d_E, int64_t n_rows, int dim, const float* 
 
 int dewi_knn_rerank_candidates(const void* d_E, int elem_type, int64_t n_rows, int dim, const float* d_Q, int n_queries,
                                const float* d_dewi32, const float* d_ent32, int k, int n_candidates, double eta,
-                               double entropy_pref, int space, int64_t* d_out_ids, float* d_out_scores,
-                               void* d_workspace, size_t workspace_bytes, void* stream) {
+                               double entropy_pref, int space, int sim_transform, int64_t* d_out_ids,
+                               float* d_out_scores, void* d_workspace, size_t workspace_bytes, void* stream) {
   if (n_candidates <= 0) return fail(DEWI_ERR_INVALID_ARG, "n_candidates must be positive (got %d)", n_candidates);
+  if (sim_transform != DEWI_SIM_RAW && sim_transform != DEWI_SIM_ONE_MINUS_DIST && sim_transform != DEWI_SIM_INV_ONE_PLUS_DIST)
+    return fail(DEWI_ERR_INVALID_ARG, "unknown sim_transform %d", sim_transform);
   return knn_rerank_impl(d_E, elem_type, n_rows, dim, d_Q, n_queries, d_dewi32, d_ent32, k, eta, entropy_pref, space,
-                         d_out_ids, d_out_scores, d_workspace, workspace_bytes, stream, n_candidates);
+                         d_out_ids, d_out_scores, d_workspace, workspace_bytes, stream, n_candidates, sim_transform);
+}
+
+int dewi_prepare_queries_bf16(const float* d_Q, int n_queries, int dim, int space, uint16_t* d_out, void* stream) {
+  if (!d_Q || !d_out) return fail(DEWI_ERR_INVALID_ARG, "null pointer");
+  if (n_queries <= 0 || dim <= 0) return fail(DEWI_ERR_INVALID_ARG, "non-positive size");
+  if (space != DEWI_SPACE_COSINE && space != DEWI_SPACE_L2) return fail(DEWI_ERR_INVALID_ARG, "unknown space %d", space);
+  hipError_t e = dewi::launch_prepare_queries_bf16(d_Q, d_out, n_queries, n_queries, dim, space, static_cast<hipStream_t>(stream));
+  return e == hipSuccess ? DEWI_OK : hip_fail(e, "prepare_queries_bf16 launch");
 }
 
 int dewi_knn_scan(const void* d_E, int elem_type, int64_t n_rows, int dim, const float* d_Q, int n_queries,
@@ -413,12 +442,8 @@ int dewi_knn_candidates(const void* d_E, int elem_type, int64_t n_rows, int dim,
     if (!d_workspace || workspace_bytes < M.total)
       return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, M.total);
     char* wsm = static_cast<char*>(d_workspace);
-    hipError_t e;
-    {
-      ScanTimer timer(stream);
-      e = dewi::launch_mfma_bf16(M, static_cast<const uint16_t*>(d_E), n_rows, dim, d_Q, n_queries, n_candidates, space, wsm,
-                                 dev.cus, stream);
-    }
+    hipError_t e = dewi::launch_mfma_bf16(M, static_cast<const uint16_t*>(d_E), n_rows, dim, d_Q, n_queries, n_candidates,
+                                          space, wsm, dev.cus, stream);
     if (e != hipSuccess) return hip_fail(e, "mfma scan launch");
     const dewi::RerankParams rp0 = make_rerank(0.0, 0.0);
     for (int g = 0; g < M.groups; ++g) {

@@ -57,6 +57,21 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// ---------------------------------------------------------------------------------------------
+// ||q|| of the cosine query preparation (reference backends.py:420-424), defined so that EVERY kernel
+// — whatever its lane layout and summation order — arrives at the same fp32 norm and therefore at
+// the same prepared query: squares and their sum in float64 (a product of two fp32 values is exact
+// there and the sum's rounding error, ~1e-13 relative, is far below fp32 resolution), then ONE
+// rounding to fp32 after the square root.  `ss` is this lane's partial sum of squares; the xor
+// butterfly leaves bit-identical totals in all 64 lanes (each step adds the same two values).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_query_norm(double ss) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, kWave);
+  return static_cast<float>(__dsqrt_rn(ss));
+}
+__device__ __forceinline__ double square_f64(float v) { return static_cast<double>(v) * static_cast<double>(v); }
+
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 #define DEWI_STEP(CTRL, MASK)                                                        \
   {                                                                                  \

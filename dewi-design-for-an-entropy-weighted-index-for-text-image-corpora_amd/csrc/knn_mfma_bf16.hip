@@ -117,9 +117,9 @@ __global__ __launch_bounds__(kWave) void prepare_queries_bf16(const float* __res
   float norm = 1.f;
   bool scale = false;
   if (space == DEWI_SPACE_COSINE) {
-    float ss = 0.f;
-    for (int j = lane; j < dim; j += kWave) ss = __builtin_fmaf(q[j], q[j], ss);
-    norm = __fsqrt_rn(wave_sum_f32(ss));
+    double ss = 0.0;   // float64: the same norm as every other kernel's (common.hpp, wave_query_norm)
+    for (int j = lane; j < dim; j += kWave) ss += square_f64(q[j]);
+    norm = wave_query_norm(ss);
     scale = norm > 0.f;
   }
   for (int j = lane; j < dim; j += kWave) {
@@ -641,19 +641,18 @@ static hipError_t run_mfma_dim(const MfmaLayout& m, const uint16_t* E, int64_t n
                                char* ws, int compute_units, hipStream_t stream) {
   constexpr int DIM = KS * 16;
   const int lds_bytes = kTileBufs * kTileRows * DIM * 2;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static PerDeviceOnce attr_once;   // one per KS instantiation
+  const hipError_t ea = attr_once.run([] {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan_bf16<KS, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan_bf16<KS, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sample_threshold_kernel<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, kMaxStagedSample * 4);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&sample_threshold_kernel<true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kMaxStagedSample * 4);
+  });
+  if (ea != hipSuccess) return ea;
   const uint16_t* qb = reinterpret_cast<const uint16_t*>(ws + m.qb_off);
   float* thr = reinterpret_cast<float*>(ws + m.thr_off);
   uint32_t* cnt = reinterpret_cast<uint32_t*>(ws + m.cnt_off);
@@ -680,10 +679,19 @@ static hipError_t run_mfma_dim(const MfmaLayout& m, const uint16_t* E, int64_t n
       hipLaunchKernelGGL(sample_threshold_kernel<false>, dim3(n_active), dim3(kSelectThreads), 0, stream, dense,
                          m.sample_stride, m.sample_stride, n_candidates, tg);
     // 3. full pass with the filter: n_blocks workgroups, each writing its own half-segments and counts
+    //    (the kernel dewi_timing_read reports: algorithmic bytes = n_rows * dim * 2 per launch)
+    timing_begin(stream);
     hipLaunchKernelGGL((mfma_scan_bf16<KS, false>), dim3(m.n_blocks), dim3(kMfmaThreads), lds_bytes, stream, E, n_rows, qg,
                        m.n_tiles, static_cast<int64_t>(1), static_cast<const float*>(tg), og,
                        static_cast<int64_t>(m.seg_cap), cg, n_active);
+    timing_end(stream);
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_prepare_queries_bf16(const float* d_Q, uint16_t* d_out, int n_queries, int n_rows_out, int dim, int space,
+                                       hipStream_t stream) {
+  hipLaunchKernelGGL(prepare_queries_bf16, dim3(n_rows_out), dim3(kWave), 0, stream, d_Q, d_out, n_queries, dim, space);
   return hipGetLastError();
 }
 

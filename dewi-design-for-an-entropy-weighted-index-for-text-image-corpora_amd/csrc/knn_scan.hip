@@ -66,15 +66,11 @@ __global__ __launch_bounds__(kScanThreads) void scan_rows_f32(const float* __res
 #pragma unroll
     for (int u = 0; u < U; ++u) qf[qi][u] = qp[u * 64];
     if constexpr (SPACE == DEWI_SPACE_COSINE) {
-      float ss = 0.f;
+      double ss = 0.0;   // float64 sum of squares: the same norm in every kernel (common.hpp, wave_query_norm)
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        ss = __builtin_fmaf(qf[qi][u].x, qf[qi][u].x, ss);
-        ss = __builtin_fmaf(qf[qi][u].y, qf[qi][u].y, ss);
-        ss = __builtin_fmaf(qf[qi][u].z, qf[qi][u].z, ss);
-        ss = __builtin_fmaf(qf[qi][u].w, qf[qi][u].w, ss);
-      }
-      const float norm = __fsqrt_rn(wave_sum_f32(ss));
+      for (int u = 0; u < U; ++u)
+        ss += square_f64(qf[qi][u].x) + square_f64(qf[qi][u].y) + square_f64(qf[qi][u].z) + square_f64(qf[qi][u].w);
+      const float norm = wave_query_norm(ss);
       if (norm > 0.f) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -253,9 +249,9 @@ __global__ __launch_bounds__(kWave) void prepare_queries_f32(const float* __rest
   float norm = 1.f;
   bool scale = false;
   if (space == DEWI_SPACE_COSINE) {
-    float ss = 0.f;
-    for (int j = lane; j < dim; j += kWave) ss = __builtin_fmaf(q[j], q[j], ss);
-    norm = __fsqrt_rn(wave_sum_f32(ss));
+    double ss = 0.0;   // float64: the same norm as every other kernel's (common.hpp, wave_query_norm)
+    for (int j = lane; j < dim; j += kWave) ss += square_f64(q[j]);
+    norm = wave_query_norm(ss);
     scale = norm > 0.f;
   }
   for (int j = lane; j < dim; j += kWave) {

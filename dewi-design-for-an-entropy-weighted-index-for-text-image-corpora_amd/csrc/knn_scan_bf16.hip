@@ -89,7 +89,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_rows_bf16(const uint16_t* _
   for (int j = 0; j < H; ++j) second[j] = (64 * j + lane) >= UPR;
 #pragma unroll
   for (int qi = 0; qi < NQ; ++qi) {
-    float ss = 0.f;
+    double ss = 0.0;   // float64 sum of squares: the same norm in every kernel (common.hpp, wave_query_norm)
 #pragma unroll
     for (int j = 0; j < H; ++j) {
       const int unit = 64 * j + lane - (second[j] ? UPR : 0);
@@ -99,13 +99,13 @@ __global__ __launch_bounds__(kScanThreads) void scan_rows_bf16(const uint16_t* _
       qf[qi][j][4] = b.x; qf[qi][j][5] = b.y; qf[qi][j][6] = b.z; qf[qi][j][7] = b.w;
       if (!second[j]) {  // the first-row units cover every column exactly once
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ss = __builtin_fmaf(qf[qi][j][i], qf[qi][j][i], ss);
+        for (int i = 0; i < 8; ++i) ss += square_f64(qf[qi][j][i]);
       }
     }
     float norm = 1.f;
     bool scale = false;
     if constexpr (SPACE == DEWI_SPACE_COSINE) {
-      norm = __fsqrt_rn(wave_sum_f32(ss));
+      norm = wave_query_norm(ss);
       scale = norm > 0.f;  // reference backends.py:422-424
     }
 #pragma unroll

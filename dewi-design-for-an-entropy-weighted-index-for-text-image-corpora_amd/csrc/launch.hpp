@@ -4,9 +4,31 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/dewi_hip.h"
 
 namespace dewi {
+
+// HIP keeps function attributes (hipFuncSetAttribute) per device: run `f` once per device this
+// process launches on, under a lock, so that two host threads — or two devices — cannot race on
+// a plain "done" flag.
+struct PerDeviceOnce {
+  std::mutex mu;
+  uint64_t done[4] = {0, 0, 0, 0};   // one bit per device ordinal (256 devices)
+  template <class F>
+  hipError_t run(F&& f) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(mu);
+    const bool tracked = dev >= 0 && dev < 256;
+    if (tracked && ((done[dev >> 6] >> (dev & 63)) & 1ull)) return hipSuccess;
+    e = f();
+    if (e == hipSuccess && tracked) done[dev >> 6] |= 1ull << (dev & 63);
+    return e;
+  }
+};
 
 // Per-wave candidate lists hold at most kMaxListCandidates keys (4 register slots x 64 lanes);
 // larger candidate counts take the dense path (one key per row, selected afterwards).
@@ -45,6 +67,11 @@ struct Tuning {
   int mfma;         // batched bf16 matrix-core path: 0 off, anything else on
 };
 
+// Measurement hooks (abi.cpp; dewi_timing_enable / dewi_timing_read): bracket the dominant corpus-pass kernel
+// of a call with hipEvents on `stream` when this call is sampled.  No-ops when timing is off.
+void timing_begin(hipStream_t stream);
+void timing_end(hipStream_t stream);
+
 ScanPlan plan_scan(int64_t n_rows, int dim, int elem_bytes, int n_candidates, int compute_units,
                    const Tuning& tuning);
 
@@ -76,6 +103,9 @@ struct MfmaLayout {
   int seg_cap;             // records per half-segment
   size_t qb_off, thr_off, cnt_off, dense_off, cand_off, total;
 };
+// Normalised (cosine, unless the norm is 0) bf16 queries, [n_rows_out][dim]; rows >= n_queries are zero.
+hipError_t launch_prepare_queries_bf16(const float* d_Q, uint16_t* d_out, int n_queries, int n_rows_out, int dim, int space,
+                                       hipStream_t stream);
 bool mfma_path_supported(int64_t n_rows, int dim, int n_queries, int n_candidates, int space);
 MfmaLayout plan_mfma(int64_t n_rows, int dim, int n_queries, int n_candidates, int compute_units);
 // Fills cand keys [groups][n_seg][256][seg_cap] and counts [groups][n_seg][256] in the workspace.
@@ -89,6 +119,8 @@ struct RerankParams {
   float w_dewi;  // fp32(eta)
   float w_ent;   // fp32(entropy_pref)
   int use_ent;   // entropy_pref != 0
+  int transform; // DEWI_SIM_* : how the raw score becomes the similarity that is blended (A10)
+  int space;     // DEWI_SPACE_* of the raw score (the transforms are defined on the library's distance)
 };
 // keys [n_queries][keys_per_query] -> top n_candidates by key -> either final (ids, scores) or
 // sorted candidate records.

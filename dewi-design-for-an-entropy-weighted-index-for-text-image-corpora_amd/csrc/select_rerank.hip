@@ -17,6 +17,13 @@ __device__ __forceinline__ int pow2_at_least(int v) {
 }
 
 __device__ __forceinline__ float blend(const RerankParams& rp, float sim, float dewi, float ent) {
+  // A10: the reference's HNSW / FAISS backends blend a similarity derived from the library's distance
+  // (backends.py:229-231 `1 - dist`; :338-341 `1.0 / (1.0 + dist)`), not the raw score.  The library's
+  // distance is 1 - <e,q> (hnswlib cosine, fp32) or the squared L2 distance (= -score in l2 space).
+  if (rp.transform != DEWI_SIM_RAW) {
+    const float dist = rp.space == DEWI_SPACE_L2 ? -sim : __fsub_rn(1.f, sim);
+    sim = rp.transform == DEWI_SIM_ONE_MINUS_DIST ? __fsub_rn(1.f, dist) : __fdiv_rn(1.f, __fadd_rn(1.f, dist));
+  }
   // reference backends.py:461-465: (1-eta)*s and eta*dewi are rounded separately, then added.
   float adj = __fadd_rn(__fmul_rn(rp.w_sim, sim), __fmul_rn(rp.w_dewi, dewi));
   if (rp.use_ent) adj = __fadd_rn(adj, __fmul_rn(rp.w_ent, ent));
@@ -636,13 +643,12 @@ hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, 
   size_t dyn = 0;
   if (d_counts != nullptr && seg.lds_keys > 0) {
     dyn = static_cast<size_t>(seg.lds_keys) * 8;
-    static bool attr_done = false;
-    if (!attr_done) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&select_rerank_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      if (e != hipSuccess) return e;
-      attr_done = true;
-    }
+    static PerDeviceOnce attr_once;
+    const hipError_t e = attr_once.run([] {
+      return hipFuncSetAttribute(reinterpret_cast<const void*>(&select_rerank_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    });
+    if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(select_rerank_kernel, dim3(n_queries), dim3(threads), dyn, stream, d_keys, keys_per_query,
                      sorted_lists, n_candidates, k, rp, d_dewi32, d_ent32, id_offset, d_out_ids, d_out_scores,

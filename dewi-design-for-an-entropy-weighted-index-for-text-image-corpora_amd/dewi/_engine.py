@@ -9,7 +9,8 @@ host<->device copies.
 from __future__ import annotations
 
 import ctypes
-from typing import Dict, Optional, Tuple, Union
+import threading
+from typing import Dict, List, Optional, Tuple, Union
 
 import numpy as np
 
@@ -45,6 +46,10 @@ class DeviceCorpus:
         self._q_pinned = None
         self._q_dev = None
         self._io: Dict[Tuple[int, int], tuple] = {}      # (batch, k) -> device + pinned result buffers of search()
+        # The blocking search() stages queries and results through per-instance buffers (pinned query, device
+        # query, cached result buffers, workspaces): one caller at a time.  The reference's ExactIndex.search is
+        # read-only and therefore safe under concurrent callers; this lock keeps that property for a threaded server.
+        self._lock = threading.RLock()
 
     # ------------------------------------------------------------------ construction
     @classmethod
@@ -144,12 +149,22 @@ class DeviceCorpus:
 
     # ------------------------------------------------------------------ hot path
     def search_device(self, q_dev, k: int, eta: float, entropy_pref: float, out_ids=None, out_scores=None,
-                      candidates: Optional[int] = None):
+                      candidates: Optional[int] = None, similarity: str = "ip"):
         """Enqueue one search on the current stream; returns device tensors, no sync.
 
         q_dev: fp32 [B, d] on this device (raw queries; cosine normalisation happens in-kernel).
         ``candidates``: size of the similarity cut that is re-ranked; default min(2k, N) as the
-        reference's ExactIndex, ``candidates=k`` gives the rule of its HNSW / FAISS backends.
+        reference's ExactIndex, ``candidates=k`` gives the rule of its HNSW / FAISS backends, whose
+        blend uses ``similarity`` = "ip" (faiss inner product, the raw score), "one_minus_dist"
+        (hnswlib: 1 - dist) or "inv_one_plus_dist" (faiss L2: 1/(1+dist)) — reference
+        backends.py:229-231, 335-338.
+
+        NOT thread-safe on one instance (shared workspaces) and it does not look at the answer: on a
+        bf16 corpus a batch of >= 2 queries takes the matrix-core path, which marks a query whose
+        survivor buffer overflowed (adversarial corpora only) with id -1 / score NaN in every slot.
+        Callers that keep results on the device must check ``unanswered(ids)`` after synchronising
+        and re-run those queries one at a time (a single query always takes the exact kernels);
+        the blocking ``search`` and ``PipelinedSearcher.drain`` do that.
         """
         torch = _torch()
         b = int(q_dev.shape[0])
@@ -164,6 +179,10 @@ class DeviceCorpus:
             out_ids = torch.empty((b, k), dtype=torch.int64, device=self.device)
         if out_scores is None:
             out_scores = torch.empty((b, k), dtype=torch.float32, device=self.device)
+        if similarity not in nat.SIM_CODES:
+            raise ValueError(f"unknown similarity {similarity!r}")
+        if candidates is None and similarity != "ip":
+            raise ValueError("similarity transforms belong to the ANN re-rank rule: pass candidates=k as well")
         ws = self._workspace(b, max(c, 1))
         if candidates is None:
             fn = self._lib.dewi_knn_rerank_bf16 if self.is_bf16 else self._lib.dewi_knn_rerank_f32
@@ -174,15 +193,36 @@ class DeviceCorpus:
             rc = self._lib.dewi_knn_rerank_candidates(
                 nat.ptr(self.emb), 1 if self.is_bf16 else 0, self.n_rows, self.dim, nat.ptr(q_dev), b, nat.ptr(self.dewi32),
                 nat.ptr(self.ent32), k, int(candidates), float(eta), float(entropy_pref), nat.SPACE_CODES[self.space],
-                nat.ptr(out_ids), nat.ptr(out_scores), nat.ptr(ws), ws.numel(), nat.stream_ptr())
+                nat.SIM_CODES[similarity], nat.ptr(out_ids), nat.ptr(out_scores), nat.ptr(ws), ws.numel(), nat.stream_ptr())
         nat.check(rc)
         return out_ids, out_scores
 
-    def search(self, queries: ArrayLike, k: int = 10, eta: float = 0.5, entropy_pref: float = 0.0,
-               candidates: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
-        """Blocking convenience: (ids int64 [B,k] including id_offset, scores fp32 [B,k]) on the host."""
+    @staticmethod
+    def unanswered(ids_host: np.ndarray) -> np.ndarray:
+        """Indices of the queries a batched matrix-core pass refused (id -1 in slot 0)."""
+        if ids_host.size == 0:
+            return np.empty(0, dtype=np.int64)
+        return np.nonzero(ids_host[:, 0] < 0)[0]
+
+    def repair_unanswered(self, q_dev, ids_host: np.ndarray, scores_host: np.ndarray, k: int, eta: float,
+                          entropy_pref: float, candidates: Optional[int] = None, similarity: str = "ip") -> int:
+        """Re-run every refused query of a finished batch alone (exact small-batch kernels) and patch
+        the host arrays in place (local row ids).  Returns how many were repaired."""
         torch = _torch()
-        with torch.cuda.device(self.device):
+        redo = self.unanswered(ids_host)
+        for j in redo.tolist():
+            sub = q_dev[j:j + 1].contiguous()
+            i2, s2 = self.search_device(sub, k, eta, entropy_pref, candidates=candidates, similarity=similarity)
+            ids_host[j] = i2.cpu().numpy()[0]
+            scores_host[j] = s2.cpu().numpy()[0]
+        return int(len(redo))
+
+    def search(self, queries: ArrayLike, k: int = 10, eta: float = 0.5, entropy_pref: float = 0.0,
+               candidates: Optional[int] = None, similarity: str = "ip") -> Tuple[np.ndarray, np.ndarray]:
+        """Blocking convenience: (ids int64 [B,k] including id_offset, scores fp32 [B,k]) on the host.
+        Safe to call from several threads on one instance (serialised by a per-corpus lock)."""
+        torch = _torch()
+        with self._lock, torch.cuda.device(self.device):
             q = self.stage_queries(queries)
             # Results come back through cached device + pinned host buffers: one async copy and ONE stream
             # synchronisation instead of two blocking pageable copies.
@@ -200,7 +240,7 @@ class DeviceCorpus:
                       dbuf, hbuf)
                 self._io[(b, kk)] = io
             if kk > 0:
-                self.search_device(q, k, eta, entropy_pref, io[0], io[1], candidates=candidates)
+                self.search_device(q, k, eta, entropy_pref, io[0], io[1], candidates=candidates, similarity=similarity)
                 io[5].copy_(io[4], non_blocking=True)
                 torch.cuda.current_stream().synchronize()
             ids_h = io[2].numpy().copy()
@@ -208,14 +248,8 @@ class DeviceCorpus:
             # The batched bf16 matrix-core path marks a query whose candidate buffer overflowed
             # (adversarial corpora, e.g. tens of thousands of duplicates of a top document) with
             # id -1: such queries are answered again by the exact small-batch kernels.
-            if ids_h.size and (ids_h[:, 0] < 0).any():
-                redo = np.nonzero(ids_h[:, 0] < 0)[0]
-                for s0 in range(0, len(redo)):               # one at a time: the exact small-batch kernels
-                    sel = redo[s0:s0 + 1]
-                    sub = q[torch.from_numpy(sel).to(q.device)].contiguous()
-                    i2, s2 = self.search_device(sub, k, eta, entropy_pref, candidates=candidates)
-                    ids_h[sel] = i2.cpu().numpy()
-                    scores_h[sel] = s2.cpu().numpy()
+            if kk > 0:
+                self.repair_unanswered(q, ids_h, scores_h, k, eta, entropy_pref, candidates, similarity)
         if self.id_offset:
             ids_h = ids_h + self.id_offset
         return ids_h, scores_h
@@ -244,6 +278,11 @@ class PipelinedSearcher:
     overlaps the scan of query i+1.  Scans themselves stay back to back on one stream: nothing
     competes with the corpus stream for HBM.  ``submit`` only enqueues; call ``drain`` (or
     synchronise the finish stream) before reading the outputs.
+
+    ``dewi_knn_scan`` / ``dewi_knn_finish`` always run the exact scan kernels (never a batched
+    matrix-core pass), so a pipelined answer is never a "refused" (-1) row: there is nothing to
+    repair after ``drain``.  The workspace size is fixed at construction from the constructing
+    thread's tuning (``_engine.tuning`` is thread-local): submit from that thread.
     """
 
     def __init__(self, corpus: DeviceCorpus, k: int, eta: float, entropy_pref: float, n_queries: int = 1,
@@ -346,6 +385,20 @@ def timing_read() -> Tuple[float, int]:
     return float(ms.value), int(n.value)
 
 
+def prepare_queries_bf16(q_dev, space: str = "cosine"):
+    """The query-preparation kernel of the batched matrix-core path on its own: normalised (cosine) bf16
+    queries [B, d] on the device (``dewi_prepare_queries_bf16``).  For parity tests and diagnostics."""
+    torch = _torch()
+    lib = nat.load_library()
+    q = q_dev.to(dtype=torch.float32).contiguous()
+    out = torch.empty(q.shape, dtype=torch.bfloat16, device=q.device)
+    with torch.cuda.device(q.device):
+        nat.check(lib.dewi_prepare_queries_bf16(nat.ptr(q), int(q.shape[0]), int(q.shape[1]), nat.SPACE_CODES[space],
+                                                nat.ptr(out), nat.stream_ptr()))
+    return out
+
+
 def tuning(scan_blocks: int = 0, rows_per_iter: int = 0, nontemporal: int = -1, batched_mfma: int = 1) -> None:
+    """Launch-shape overrides of the CALLING THREAD (the library keeps them thread-local)."""
     nat.check(nat.load_library().dewi_tuning_set(int(scan_blocks), int(rows_per_iter), int(nontemporal),
                                                  int(batched_mfma)))

@@ -23,7 +23,7 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 
-from .types import Payload, payload_columns
+from .types import PAYLOAD_FIELDS, Payload, PayloadStore, payload_columns
 
 logger = logging.getLogger(__name__)
 
@@ -122,7 +122,8 @@ class ExactIndex(BaseIndex):
     eta blend, then top-k), same on-disk format.  Differences, all additive:
 
     * ``add_batch`` / ``search_batch`` bulk entry points (the reference is one row / one
-      query per call);
+      query per call), and ``add_batch_columns`` (payloads as arrays: no Python object per row;
+      ``Payload`` objects are made on demand for the rows a search returns);
     * rows are normalised by a device kernel at ``build`` (not on the host at ``add``), so
       stored rows can differ from the reference's in the last fp32 bit;
     * the payload values the re-rank reads (``dewi``, ``ht_mean``, ``hi_mean``) are
@@ -132,6 +133,7 @@ class ExactIndex(BaseIndex):
 
     def __init__(self, dim: int, space: str = "cosine", **kwargs: Any):
         super().__init__(dim, space, **kwargs)
+        self._payloads = PayloadStore()            # a dict (reference contract) that also serves column-ingested rows
         self._normalize = space == "cosine"
         self._pending: List[np.ndarray] = []      # raw fp32 rows (or [m, d] blocks) not yet on the device
         self._pending_rows = 0
@@ -160,6 +162,30 @@ class ExactIndex(BaseIndex):
         self._doc_ids.extend(doc_ids)
         self._payloads.update(zip(doc_ids, payloads))
         self._pending.append(np.array(emb, dtype=np.float32))
+        self._pending_rows += emb.shape[0]
+        self._invalidate()
+
+    def add_batch_columns(self, doc_ids: Sequence[str], embeddings: np.ndarray, columns: Dict[str, np.ndarray],
+                          copy: bool = False) -> None:
+        """Bulk ``add`` with the payloads as structure-of-arrays: ``columns[name]`` is one
+        float array per ``Payload`` field (missing fields are 0.0, as ``Payload()``'s defaults).  Nothing
+        is done per row in Python: a 1 M-row ingest is a list extend plus array bookkeeping, and
+        ``build`` uploads the columns as they are.  ``Payload`` objects are created lazily — for the
+        rows a search returns, or on ``get_payload`` / iteration over ``_payloads`` — and the same
+        object is returned from then on.  ``copy=False``: the embedding block is referenced, not
+        copied, until ``build()``; do not modify it in between."""
+        emb = np.asarray(embeddings)
+        if emb.ndim != 2 or emb.shape[1] != self.dim:
+            raise ValueError(f"Expected embeddings of shape (m, {self.dim}), got {emb.shape}")
+        if len(doc_ids) != emb.shape[0]:
+            raise ValueError("doc_ids and embeddings must have the same length")
+        unknown = [name for name in columns if name not in PAYLOAD_FIELDS]
+        if unknown:
+            raise ValueError(f"unknown payload columns {unknown}")
+        row0 = len(self._doc_ids)
+        self._payloads.add_columns(row0, doc_ids, columns)         # validates the column shapes
+        self._doc_ids.extend(doc_ids)
+        self._pending.append(np.array(emb, dtype=np.float32) if copy else np.ascontiguousarray(emb, dtype=np.float32))
         self._pending_rows += emb.shape[0]
         self._invalidate()
 
@@ -199,11 +225,14 @@ class ExactIndex(BaseIndex):
             head = DeviceCorpus.from_host(rows, cols["dewi"], cols["ht_mean"], cols["hi_mean"], self.space,
                                           normalize=False, device=self._device)
             if already < rows.shape[0]:
+                import torch
                 from . import _native as nat
                 tail = head.emb[already:]
-                nat.check(nat.load_library().dewi_normalize_rows_f32(nat.ptr(tail), nat.ptr(tail),
-                                                                     rows.shape[0] - already, self.dim,
-                                                                     nat.stream_ptr()))
+                with torch.cuda.device(head.device):       # the kernel goes on THAT device's current stream
+                    nat.check(nat.load_library().dewi_normalize_rows_f32(nat.ptr(tail), nat.ptr(tail),
+                                                                         rows.shape[0] - already, self.dim,
+                                                                         nat.stream_ptr()))
+                    torch.cuda.current_stream().synchronize()
             corpus = head
         self._corpus = corpus
         self._pending = []
@@ -213,8 +242,29 @@ class ExactIndex(BaseIndex):
         self._is_trained = True
 
     def _payload_columns(self) -> Dict[str, np.ndarray]:
-        plist = [self._payloads[d] for d in self._doc_ids]
-        return payload_columns(plist, ("dewi", "ht_mean", "hi_mean"))
+        """float64 ``dewi`` / ``ht_mean`` / ``hi_mean`` of every row, in row order.  Column-ingested
+        blocks are copied as arrays (objects already handed out for some of their rows win, so in-place
+        edits of a returned ``Payload`` are seen by ``refresh_payloads``); the rest is read from objects."""
+        fields = ("dewi", "ht_mean", "hi_mean")
+        n = len(self._doc_ids)
+        store = self._payloads
+        out = {name: np.zeros(n, dtype=np.float64) for name in fields}
+        covered = np.zeros(n, dtype=bool)
+        for row0, row1, cols, made in store.column_blocks():
+            for name in fields:
+                if name in cols:
+                    out[name][row0:row1] = cols[name]
+            for row, p in made.items():
+                for name in fields:
+                    out[name][row] = getattr(p, name)
+            covered[row0:row1] = True
+        if not covered.all():
+            rows = np.nonzero(~covered)[0]
+            plist = [dict.__getitem__(store, self._doc_ids[r]) for r in rows.tolist()]
+            sub = payload_columns(plist, fields)
+            for name in fields:
+                out[name][rows] = sub[name]
+        return out
 
     def refresh_payloads(self) -> None:
         """Re-snapshot ``dewi`` / ``ht_mean`` / ``hi_mean`` of every Payload into the HBM columns."""
@@ -262,37 +312,37 @@ class ExactIndex(BaseIndex):
             self.build()
 
     def search(self, query: np.ndarray, k: int = 10, eta: float = 0.5, entropy_pref: float = 0.0,
-               candidates: Optional[int] = None) -> SearchResult:
+               candidates: Optional[int] = None, similarity: str = "ip") -> SearchResult:
         """Reference ``ExactIndex.search`` (backends.py:414-481) for one query.
 
         ``candidates`` (additive): how many nearest rows are re-ranked.  Default ``min(2k, N)``, the
         reference's ExactIndex rule; ``candidates=k`` is the rule of its HNSW / FAISS backends
-        (backends.py:217-240, 326-356: exactly k neighbours are blended and sorted) on exact neighbours.
+        (backends.py:217-240, 326-356: exactly k neighbours are blended and sorted) on exact neighbours,
+        with ``similarity`` choosing what those backends blend: "ip" (faiss inner product, :335-336),
+        "one_minus_dist" (hnswlib ``1 - dist``, :229-231) or "inv_one_plus_dist" (faiss L2
+        ``1/(1+dist)``, :337-338).  hnswlib / faiss are not installed here: that rule is restated by
+        reading and its parity is unpinned.
         """
         q = np.asarray(query, dtype=np.float32)
         if q.ndim == 1:
             q = q.reshape(1, -1)
-        rows, scores = self.search_batch(q, k, eta, entropy_pref, candidates)
-        ids, pay = self._doc_ids, self._payloads
-        out: SearchResult = []
-        for r, s in zip(rows[0].tolist(), scores[0].tolist()):
-            doc_id = ids[r]
-            out.append((doc_id, float(s), pay[doc_id]))
-        return out
+        rows, scores = self.search_batch(q, k, eta, entropy_pref, candidates, similarity)
+        return self.results_for(rows[:1], scores[:1])[0]
 
     def search_batch(self, queries: np.ndarray, k: int = 10, eta: float = 0.5, entropy_pref: float = 0.0,
-                     candidates: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
+                     candidates: Optional[int] = None, similarity: str = "ip") -> Tuple[np.ndarray, np.ndarray]:
         """[B, dim] queries -> (row indices int64 [B, k], adjusted scores fp32 [B, k])."""
         self._ensure_built()
         q = np.asarray(queries, dtype=np.float32)
         if q.ndim != 2 or q.shape[1] != self.dim:
             raise ValueError(f"Expected queries of shape (B, {self.dim}), got {q.shape}")
-        return self._corpus.search(q, int(k), float(eta), float(entropy_pref), candidates=candidates)
+        return self._corpus.search(q, int(k), float(eta), float(entropy_pref), candidates=candidates,
+                                   similarity=similarity)
 
     def results_for(self, rows: np.ndarray, scores: np.ndarray) -> List[SearchResult]:
         """Row indices/scores of ``search_batch`` -> the reference's (doc_id, score, Payload) tuples."""
-        ids, pay = self._doc_ids, self._payloads
-        return [[(ids[r], float(s), pay[ids[r]]) for r, s in zip(rr.tolist(), ss.tolist())]
+        ids, at_row = self._doc_ids, self._payloads.at_row
+        return [[(ids[r], float(s), at_row(r, ids[r])) for r, s in zip(rr.tolist(), ss.tolist())]
                 for rr, ss in zip(rows, scores)]
 
     # ---------------------------------------------------------------- persistence (reference :483-556)

@@ -56,6 +56,11 @@ class DewiIndex(BaseIndex):
         self._backend.add_batch(doc_ids, np.asarray(embeddings, dtype=np.float32), payloads)
         self._built = False
 
+    def add_batch_columns(self, doc_ids: Sequence[str], embeddings: np.ndarray, columns: Dict[str, np.ndarray]) -> None:
+        """Bulk ingest with the payloads as one float array per ``Payload`` field (no object per row)."""
+        self._backend.add_batch_columns(doc_ids, embeddings, columns)
+        self._built = False
+
     def build(self) -> None:
         self._backend.build()
         self._built = True

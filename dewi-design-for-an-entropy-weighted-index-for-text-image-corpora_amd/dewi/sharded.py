@@ -36,8 +36,11 @@ class ShardedSearcher:
     """Search over a corpus sharded by doc id; one instance per rank."""
 
     def __init__(self, local, n_local: int, group=None, scan_fn: Optional[Callable] = None,
-                 merge_fn: Optional[Callable] = None, device=None):
+                 merge_fn: Optional[Callable] = None, device=None, always_collective: bool = False):
         """``local``: this rank's ``DeviceCorpus`` (or any object, when ``scan_fn`` is given).
+
+        ``always_collective``: run the all-gather even in a group of one rank (by default a lone rank
+        skips it) — the single-GPU rehearsal of the RCCL path used by the tests and by ``bench.py``.
 
         ``scan_fn(queries, c) -> int32 tensor [B, c, 4]`` of records sorted by (sim desc, id asc)
         with ids already global and ``id = -1`` padding; ``merge_fn(lists[world, B, c, 4], c, k,
@@ -51,6 +54,7 @@ class ShardedSearcher:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
+        self.always_collective = bool(always_collective) and dist.is_initialized()
         self.device = device if device is not None else getattr(local, "device", torch.device("cpu"))
         # exclusive prefix sum of the shard sizes = id offsets; all ranks learn every size
         sizes = [int(n_local)]
@@ -78,7 +82,7 @@ class ShardedSearcher:
     def exchange(self, recs):
         """all-gather [B, c, 4] int32 records -> [world, B, c, 4] on every rank."""
         torch, dist = self._torch, self._dist
-        if self.world == 1:
+        if self.world == 1 and not self.always_collective:
             return recs.unsqueeze(0)
         if self.backend == "nccl":
             out = torch.empty((self.world,) + tuple(recs.shape), dtype=recs.dtype, device=recs.device)
@@ -196,15 +200,17 @@ class ShardedRobustFit:
     rehearsed with ``gloo`` on CPU-only hosts; there is no CPU implementation in this package.
     """
 
-    def __init__(self, steps, n_local: int, group=None):
+    def __init__(self, steps, n_local: int, group=None, always_collective: bool = False):
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
         self.steps, self.group = steps, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
+        # run the all-reduces even in a group of one rank (single-GPU rehearsal of the RCCL path)
+        self.always_collective = bool(always_collective) and dist.is_initialized()
         n = torch.tensor([int(n_local)], dtype=torch.int64)
-        if self.world > 1:
+        if self.world > 1 or self.always_collective:
             if self.backend == "nccl":
                 n = n.cuda()
             dist.all_reduce(n, group=group)
@@ -215,7 +221,7 @@ class ShardedRobustFit:
             raise NotImplementedError("sharded fit sums int32 histogram counts: n_total must be below 2^31")
 
     def _sum_over_ranks(self, t):
-        if self.world == 1:
+        if self.world == 1 and not self.always_collective:
             return
         dist = self._dist
         if self.backend == "nccl" or not t.is_cuda:

@@ -10,7 +10,8 @@ from __future__ import annotations
 
 import dataclasses
 import json
-from typing import Dict, Iterable, Mapping, Sequence
+import bisect
+from typing import Dict, Iterable, Iterator, List, Mapping, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -80,3 +81,117 @@ def payloads_from_columns(columns: Mapping[str, np.ndarray]) -> list:
     n = len(next(iter(columns.values()))) if columns else 0
     cols = [np.asarray(columns[name], dtype=np.float64).tolist() for name in names]
     return [Payload(**{name: col[i] for name, col in zip(names, cols)}) for i in range(n)]
+
+
+class PayloadStore(dict):
+    """``doc_id -> Payload`` as the reference's ``BaseIndex._payloads`` (backends.py:63), for corpora
+    that may have been ingested as COLUMNS (``ExactIndex.add_batch_columns``).
+
+    Documents added with a ``Payload`` object are plain dict entries (the object the caller passed is
+    the object every lookup returns).  Column-ingested documents have no object until somebody asks
+    for one: the first lookup builds a ``Payload`` from the columns and keeps it, so later lookups
+    return the same object.  Bulk views (iteration, ``items``, ``values``, ``len`` is cheap) materialise
+    whatever is still missing.
+    """
+
+    def __init__(self) -> None:
+        super().__init__()
+        self._starts: List[int] = []          # first global row of each column block
+        self._blocks: List[Tuple[int, int, Sequence[str], Dict[str, np.ndarray]]] = []   # (row0, row1, ids, columns)
+        self._made: List[Dict[int, "Payload"]] = []      # per block: rows that already have an object
+        self._id_rows: Optional[Dict[str, int]] = None    # doc_id -> global row of column-ingested docs (lazy)
+        self._lazy_count = 0
+
+    # ---- ingest -----------------------------------------------------------------------------
+    def add_columns(self, row0: int, doc_ids: Sequence[str], columns: Mapping[str, np.ndarray]) -> None:
+        cols = {name: np.asarray(columns[name], dtype=np.float64) for name in PAYLOAD_FIELDS if name in columns}
+        n = len(doc_ids)
+        for name, c in cols.items():
+            if c.shape != (n,):
+                raise ValueError(f"payload column {name!r} has shape {c.shape}, expected ({n},)")
+        self._starts.append(int(row0))
+        self._blocks.append((int(row0), int(row0) + n, doc_ids, cols))
+        self._made.append({})
+        self._id_rows = None
+        self._lazy_count += n
+
+    # ---- row access (search results: no doc_id -> row map needed) -----------------------------
+    def _block_of(self, row: int) -> int:
+        j = bisect.bisect_right(self._starts, row) - 1
+        if j < 0 or row >= self._blocks[j][1]:
+            return -1
+        return j
+
+    def at_row(self, row: int, doc_id: str) -> "Payload":
+        hit = dict.get(self, doc_id)
+        if hit is not None:
+            return hit
+        j = self._block_of(row)
+        if j < 0:
+            raise KeyError(doc_id)
+        return self._make(j, row, doc_id)
+
+    def _make(self, j: int, row: int, doc_id: str) -> "Payload":
+        row0, _, _, cols = self._blocks[j]
+        p = Payload(**{name: float(c[row - row0]) for name, c in cols.items()})
+        dict.__setitem__(self, doc_id, p)
+        self._made[j][row] = p
+        self._lazy_count -= 1
+        return p
+
+    def column_blocks(self) -> Iterator[Tuple[int, int, Dict[str, np.ndarray], Dict[int, "Payload"]]]:
+        """(row0, row1, columns, objects already handed out for rows of the block)."""
+        for (row0, row1, _, cols), made in zip(self._blocks, self._made):
+            yield row0, row1, cols, made
+
+    # ---- mapping protocol -----------------------------------------------------------------------
+    def _rows_by_id(self) -> Dict[str, int]:
+        if self._id_rows is None:
+            m: Dict[str, int] = {}
+            for row0, _, ids, _ in self._blocks:
+                m.update(zip(ids, range(row0, row0 + len(ids))))
+            self._id_rows = m
+        return self._id_rows
+
+    def __missing__(self, doc_id: str) -> "Payload":
+        row = self._rows_by_id().get(doc_id) if self._blocks else None
+        if row is None:
+            raise KeyError(doc_id)
+        return self._make(self._block_of(row), row, doc_id)
+
+    def get(self, doc_id, default=None):
+        try:
+            return self[doc_id]
+        except KeyError:
+            return default
+
+    def __contains__(self, doc_id) -> bool:
+        return dict.__contains__(self, doc_id) or (bool(self._blocks) and doc_id in self._rows_by_id())
+
+    def __len__(self) -> int:
+        return dict.__len__(self) + self._lazy_count
+
+    def materialize_all(self) -> None:
+        if self._lazy_count:
+            for j, (row0, _, ids, _) in enumerate(self._blocks):
+                made = self._made[j]
+                for i, doc_id in enumerate(ids):
+                    if row0 + i not in made and not dict.__contains__(self, doc_id):
+                        self._make(j, row0 + i, doc_id)
+            self._lazy_count = 0
+
+    def __iter__(self):
+        self.materialize_all()
+        return dict.__iter__(self)
+
+    def keys(self):
+        self.materialize_all()
+        return dict.keys(self)
+
+    def values(self):
+        self.materialize_all()
+        return dict.values(self)
+
+    def items(self):
+        self.materialize_all()
+        return dict.items(self)

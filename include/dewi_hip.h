@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DEWI_ABI_VERSION 1
+#define DEWI_ABI_VERSION 2
 
 /* status codes */
 #define DEWI_OK 0
@@ -43,6 +43,14 @@ extern "C" {
 /* `space` argument (reference: ExactIndex(space=...), backends.py:389-392) */
 #define DEWI_SPACE_COSINE 0 /* query is L2-normalised unless its norm is 0; score = <e, q>            */
 #define DEWI_SPACE_L2 1     /* nothing is normalised; score = -sum((e - q)^2)                       */
+
+/* `sim_transform` argument of dewi_knn_rerank_candidates: how a neighbour's raw score becomes the
+ * similarity the blend uses in the reference's ANN backends.  `dist` is the distance the ANN library
+ * would report for that neighbour: 1 - <e,q> in cosine space (hnswlib, fp32), the squared L2 distance
+ * (= -score) in l2 space. */
+#define DEWI_SIM_RAW 0               /* sim = score             faiss inner product  (backends.py:335-336)  */
+#define DEWI_SIM_ONE_MINUS_DIST 1    /* sim = 1 - dist          hnswlib              (backends.py:229-231)  */
+#define DEWI_SIM_INV_ONE_PLUS_DIST 2 /* sim = 1 / (1 + dist)    faiss L2             (backends.py:337-338)  */
 
 /* `mode` argument of dewi_score_f64 (reference: DewiScorer.score / score_conditional) */
 #define DEWI_MODE_STANDARD 0
@@ -67,7 +75,8 @@ typedef struct dewi_candidate {
 int dewi_abi_version(void);
 const char* dewi_last_error(void);
 
-/* Device facts the planner uses (compute units, wavefront size); calls hipGetDeviceProperties once. */
+/* Facts of the calling thread's CURRENT device that the planner uses (compute units, wavefront size);
+ * hipGetDeviceProperties is called once per device ordinal and cached under a lock. */
 int dewi_device_info(int* out_compute_units, int* out_wavefront, size_t* out_total_mem);
 
 /* ------------------------------------------------------------------------------------------
@@ -113,11 +122,20 @@ int dewi_knn_rerank_f32(const float* d_E, int64_t n_rows, int dim, const float* 
 /* A10 / F4  the same search with an explicit candidate count instead of min(2k, n_rows): n_candidates =
  * k reproduces the re-rank rule of the reference's HNSWIndex / FAISSIndex.search (backends.py:204-241,
  * 309-356: the library returns exactly k neighbours, which are then blended and sorted) on top of an
- * exact neighbour search.  k <= n_candidates; elem_type 0 fp32, 1 bf16. */
+ * exact neighbour search.  k <= n_candidates; elem_type 0 fp32, 1 bf16.  sim_transform (DEWI_SIM_*) selects the
+ * similarity those backends blend: the raw inner product (faiss), `1 - dist` (hnswlib) or `1/(1+dist)` (faiss
+ * L2); fp32 arithmetic, one rounding per operation.  hnswlib / faiss themselves are not part of this build
+ * and were not available to check against: parity of this entry point is UNPINNED (restated by reading). */
 int dewi_knn_rerank_candidates(const void* d_E, int elem_type, int64_t n_rows, int dim, const float* d_Q, int n_queries,
                                const float* d_dewi32, const float* d_ent32, int k, int n_candidates, double eta,
-                               double entropy_pref, int space, int64_t* d_out_ids, float* d_out_scores,
-                               void* d_workspace, size_t workspace_bytes, void* stream);
+                               double entropy_pref, int space, int sim_transform, int64_t* d_out_ids,
+                               float* d_out_scores, void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* Step 1 of the bf16 search alone (backends.py:420-424 followed by the bf16 rounding of config C3): q / ||q||
+ * in fp32 unless the norm is 0 (cosine), then round-to-nearest-even to bf16.  This is the kernel the batched
+ * matrix-core path runs on its queries; exposed so that parity tests can check the normalisation on its own
+ * and feed the oracle the very same prepared queries.  d_out [n_queries][dim] bf16. */
+int dewi_prepare_queries_bf16(const float* d_Q, int n_queries, int dim, int space, uint16_t* d_out, void* stream);
 
 /* The same search split at the kernel boundary, for callers that keep several queries in flight:
  * dewi_knn_scan enqueues steps 1-3a (corpus scan, per-workgroup candidate lists -> workspace) and
@@ -226,7 +244,9 @@ int dewi_timing_enable(int every);
 int dewi_timing_read(double* out_mean_scan_ms, int* out_launches);
 
 /* Launch-shape overrides for tuning sweeps (0 / -1 = planner default).  batched_mfma = 0 disables the
- * matrix-core path of dewi_knn_rerank_bf16 (every batch then takes the small-batch scan kernels). */
+ * matrix-core paths (every batch then takes the small-batch scan kernels).  The setting belongs to the
+ * CALLING THREAD (thread-local): it changes the plan, and with it dewi_knn_workspace_bytes, only for calls
+ * made from the same thread, so one thread's sweep cannot invalidate another thread's workspace. */
 int dewi_tuning_set(int scan_blocks, int rows_per_iter, int nontemporal, int batched_mfma);
 
 #ifdef __cplusplus

@@ -209,6 +209,29 @@ def ann_rerank(neigh_idx: np.ndarray, neigh_sim: np.ndarray, dewi: np.ndarray, h
     return neigh_idx[order], adj[order]
 
 
+def ann_library_distance(E: np.ndarray, q_prepared: np.ndarray, space: str = "cosine") -> np.ndarray:
+    """The distance an ANN library reports for each row, as the reference's backends consume it: hnswlib's
+    cosine / inner-product spaces return ``1.0f - <e, q>`` (fp32); hnswlib ``l2`` and faiss ``METRIC_L2`` return
+    the squared L2 distance.  (faiss ``METRIC_INNER_PRODUCT`` returns the inner product itself, which
+    backends.py:335-336 uses as the score directly.)  Restated from the libraries' documented behaviour:
+    hnswlib >=0.7,<0.8 and faiss-cpu >=1.7 (pyproject.toml:60-64) are not installed — parity unpinned."""
+    s = similarities(E, np.asarray(q_prepared, dtype=np.float32), space)
+    return (np.float32(1.0) - s).astype(np.float32) if space == "cosine" else (-s).astype(np.float32)
+
+
+def ann_similarity(dist: np.ndarray, kind: str) -> np.ndarray:
+    """Neighbour distance -> the similarity the reference blends.  ``one_minus_dist``: backends.py:229-231
+    ``(1 - dist)`` (HNSWIndex); ``inv_one_plus_dist``: backends.py:337-338 ``1.0 / (1.0 + dist)`` (FAISSIndex
+    with METRIC_L2).  ``dist`` is an fp32 scalar in the reference; under NumPy >= 2 (NEP 50) Python scalars are
+    weak, so both expressions stay fp32."""
+    d = np.asarray(dist, dtype=np.float32)
+    if kind == "one_minus_dist":
+        return (np.float32(1.0) - d).astype(np.float32)
+    if kind == "inv_one_plus_dist":
+        return (np.float32(1.0) / (np.float32(1.0) + d)).astype(np.float32)
+    raise ValueError(f"unknown similarity transform {kind!r}")
+
+
 # ---------------------------------------------------------------------------
 # A6 — scorer.RobustStats.fit                     src/dewi/scorer.py:18-26
 # ---------------------------------------------------------------------------

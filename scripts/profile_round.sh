@@ -1,0 +1,41 @@
+#!/bin/bash
+# Round profile of the bench harness on the GPU box (run from the repo root):
+#   bash scripts/profile_round.sh <tag> [commit]
+# 1. rocprofv3 --kernel-trace --stats of the default bench command (c2), of --config c3 and --config c5
+# 2. PMC passes, ONE COUNTER SET PER RUN and never together with a trace domain: FETCH_SIZE, WRITE_SIZE (c2, c3),
+#    then the SQ counters of the matrix-core kernel (c3): LDS bank conflicts, MFMA / VALU busy, wait cycles
+# 3. scripts/summarize_pmc.py -> pmc_summary.{txt,json} and hbm_traffic.json (bench.py's roofline.traffic)
+# The program itself (python3 bench.py) follows `--` directly: no env/bash hop under the profiler.
+set -e
+TAG=${1:-r02}
+COMMIT=${2:-unknown}
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+Q="--cpu-queries 0 --latency-queries 0"
+trace() {   # name, bench args...
+  local name=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$name -o bench -- python3 bench.py "$@" $Q > $OUT/bench_under_trace_$name.json 2> $OUT/trace_$name.err || { tail -20 $OUT/trace_$name.err; exit 1; }
+  find $OUT/trace_$name -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_$name.csv
+  head -12 $OUT/kernel_stats_$name.csv
+}
+pmc() {     # dir suffix, counters (space separated in one string), bench args...
+  local name=$1; local ctr=$2; shift; shift
+  if rocprofv3 --pmc $ctr --output-format csv -d $OUT/pmc_$name -o bench -- python3 bench.py "$@" $Q > $OUT/bench_under_pmc_$name.json 2> $OUT/pmc_$name.err; then
+    echo "pmc pass $name done"
+  else
+    echo "pmc pass $name FAILED (counter set: $ctr)"; tail -5 $OUT/pmc_$name.err
+  fi
+}
+trace c2 --steps 300 --warmup 30
+trace c3 --config c3 --steps 40 --warmup 5
+trace c5 --config c5 --steps 20 --warmup 3
+pmc FETCH_SIZE_c2 FETCH_SIZE --steps 40 --warmup 5
+pmc WRITE_SIZE_c2 WRITE_SIZE --steps 40 --warmup 5
+pmc FETCH_SIZE_c3 FETCH_SIZE --config c3 --steps 10 --warmup 2
+pmc WRITE_SIZE_c3 WRITE_SIZE --config c3 --steps 10 --warmup 2
+pmc SQ_LDS_c3 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES" --config c3 --steps 10 --warmup 2
+pmc SQ_MFMA_c3 "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM" --config c3 --steps 10 --warmup 2
+pmc SQ_WAIT_c3 "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" --config c3 --steps 10 --warmup 2
+python3 scripts/summarize_pmc.py $OUT --commit $COMMIT --record "1000000x768x4xB1=scan_rows_f32" "1000000x768x2xB256=mfma_scan_bf16<48, false>" > $OUT/pmc_summary.txt
+cat $OUT/pmc_summary.txt

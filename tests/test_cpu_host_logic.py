@@ -141,3 +141,93 @@ def test_public_api_accepts_every_reference_call(golden_dir):
                 assert i < len(mine) and mine[i].name == pname, f"{qual}.{mname}: parameter {i} should be {pname}"
                 got = None if mine[i].default is inspect.Parameter.empty else repr(mine[i].default)
                 assert got == default, f"{qual}.{mname}({pname}): default {got} != {default}"
+
+
+def test_payload_store_serves_objects_and_columns():
+    """dewi.types.PayloadStore: the reference's doc_id -> Payload dict for corpora ingested as columns."""
+    from dewi.types import Payload, PayloadStore
+    st = PayloadStore()
+    a = Payload(dewi=1.0)
+    st["a"] = a
+    st.add_columns(1, ["b", "c", "d"], {"dewi": np.array([.1, .2, .3]), "ht_mean": np.array([1., 2., 3.])})
+    assert len(st) == 4 and "c" in st and "z" not in st and dict.__len__(st) == 1     # nothing materialised yet
+    p = st.at_row(2, "c")
+    assert p.dewi == .2 and p.ht_mean == 2.0 and p.noise == 0.0
+    assert st["c"] is p and st.get("c") is p and st.at_row(2, "c") is p              # one object per document
+    assert st["a"] is a and st.get("zz") is None and len(st) == 4
+    with pytest.raises(KeyError):
+        st["zz"]
+    blocks = list(st.column_blocks())
+    assert blocks[0][0] == 1 and blocks[0][1] == 4 and set(blocks[0][3]) == {2}
+    assert sorted(st.keys()) == ["a", "b", "c", "d"] and len(st) == 4 and len(list(st.items())) == 4
+    with pytest.raises(ValueError, match="shape"):
+        st.add_columns(4, ["e"], {"dewi": np.zeros(3)})
+
+
+def test_column_ingest_host_side_bookkeeping():
+    """ExactIndex.add_batch_columns mixed with add(): row-ordered float64 payload columns for the device."""
+    from dewi.backends import ExactIndex
+    from dewi.types import Payload
+    idx = ExactIndex(dim=4)
+    idx.add("x", np.ones(4, np.float32), Payload(dewi=0.9, ht_mean=2.0, hi_mean=4.0))
+    idx.add_batch_columns(["p", "q"], np.ones((2, 4), np.float32), {"dewi": np.array([.1, .2]), "hi_mean": np.array([6., 8.])})
+    idx.add("y", np.ones(4, np.float32), Payload(dewi=0.5))
+    cols = idx._payload_columns()
+    assert cols["dewi"].tolist() == [0.9, 0.1, 0.2, 0.5]
+    assert cols["ht_mean"].tolist() == [2.0, 0.0, 0.0, 0.0] and cols["hi_mean"].tolist() == [4.0, 6.0, 8.0, 0.0]
+    idx._payloads["q"].dewi = 7.0                       # an object handed out for a column row wins afterwards
+    assert idx._payload_columns()["dewi"].tolist() == [0.9, 0.1, 7.0, 0.5]
+    assert idx._doc_ids == ["x", "p", "q", "y"] and len(idx._payloads) == 4
+
+
+def test_blocking_search_is_serialised_per_corpus():
+    """DeviceCorpus.search stages through per-instance buffers, so it must hold the corpus lock from
+    staging to copy-out.  Checked without a GPU on a stand-in instance whose device steps are stubs that
+    record whether the lock was held."""
+    import threading
+    import torch
+    from dewi import _engine as eng
+    c = eng.DeviceCorpus.__new__(eng.DeviceCorpus)
+    c._lock = threading.RLock()
+    c.device = torch.device("cpu")
+    c.id_offset = 0
+    c._io = {}
+    held = []
+
+    def owned():
+        # an RLock held by THIS thread can be re-acquired; probing from another thread tells if it is held at all
+        res = []
+
+        def probe():
+            got = c._lock.acquire(blocking=False)
+            if got:
+                c._lock.release()
+            res.append(got)
+        t = threading.Thread(target=probe)
+        t.start()
+        t.join()
+        return not res[0]
+    c.stage_queries = lambda q: (held.append(owned()), torch.zeros((1, 4)))[1]
+    c.search_device = lambda *a, **kw: held.append(owned())
+    c.repair_unanswered = lambda *a, **kw: held.append(owned()) or 0
+
+    class _NoDev:
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+    real_device, real_empty, real_sync = torch.cuda.device, torch.empty, torch.cuda.current_stream
+    torch.cuda.device = lambda d: _NoDev()
+    torch.empty = lambda *a, **kw: real_empty(*a, **{k: v for k, v in kw.items() if k not in ("device", "pin_memory")})
+
+    class _S:
+        def synchronize(self):
+            held.append(owned())
+    torch.cuda.current_stream = lambda: _S()
+    try:
+        ids, sc = c.search(np.zeros(4, np.float32), k=2)
+    finally:
+        torch.cuda.device, torch.empty, torch.cuda.current_stream = real_device, real_empty, real_sync
+    assert ids.shape == (1, 2) and held and all(held), held
+    assert not owned()                                   # released afterwards

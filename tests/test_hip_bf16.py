@@ -1,19 +1,21 @@
 """GPU parity tests of the bf16-corpus search (config C3's storage) through the C ABI.
 
 Oracle: the fp32 restatement of the reference run on bf16-ROUNDED inputs (products of bf16 values
-are exact in fp32).  Tolerance: the GPU and NumPy normalise the query with differently ordered fp32
-sums, so a query element that sits on a bf16 rounding boundary can round the other way (one bf16
-ulp = 2^-8 relative on ONE of the d products, <= ~5e-6 on a unit-norm score).  Scores are therefore
-compared to 2e-5 and the id ranking only where decision gaps exceed 2e-5.
+are exact in fp32).  The GPU and NumPy normalise the query with differently computed norms, so a query
+element that sits on a bf16 rounding boundary can round the other way (one bf16 ulp on ONE of the d
+products, <= ~5e-6 on a unit-norm score).  To keep that out of the ranking comparison the tests check the
+query preparation on its own (``parity.device_prepared_queries``: within one bf16 ulp of the oracle's,
+>= 99 % bit-equal) and then run the oracle on the device-prepared queries: what is left is fp32 summation
+order, so ids are compared exactly wherever decision gaps exceed 1e-6 and scores to 1e-5.
 """
 import numpy as np
 import pytest
 
 import dewi_oracle as orc
-from parity import check_batch
+from parity import check_batch, device_prepared_queries
 
 pytestmark = pytest.mark.gpu
-TOL = dict(gap=2e-5, score_tol=2e-5, prepared=True)
+TOL = dict(gap=1e-6, score_tol=1e-5, prepared=True)
 
 
 def _setup(n, dim, seed):
@@ -35,13 +37,11 @@ def test_bf16_search_vs_oracle(dim, n):
     """Fast pair-of-rows kernel (dim = 256*H, odd and even row counts), 16-byte generic, scalar generic."""
     cb, Eb, dewi32, ent32 = _setup(n, dim, seed=dim + n)
     Q = orc.synth_queries(5, dim, seed=dim)
-    Qp = np.stack([orc.bf16_round(orc.prepare_query(q)) for q in Q])
+    Qp = device_prepared_queries(Q)
     for k, eta, pref in ((10, 0.3, 0.0), (1, 0.5, 0.0), (100, 0.25, 0.3), (150, 0.5, 0.0)):
         ids, sc = cb.search(Q, k, eta, pref)
-        # with 100+ results some adjacent pair is almost always closer than 2e-5: those queries are
-        # checked as score multisets only, so no bound on their share
         check_batch(Eb, Qp, dewi32, ent32, k, eta, pref, "cosine", ids, sc,
-                    max_excluded_frac=0.6 if k <= 10 else 1.0, **TOL)
+                    min_decisive_frac=0.8 if k <= 10 else 0.5, **TOL)
 
 
 def test_bf16_sharded_equals_whole():
@@ -83,7 +83,7 @@ def test_bf16_randomised_shapes_vs_oracle(case):
     n, dim, b, k, eta, pref = case
     cb, Eb, dewi32, ent32 = _setup(n, dim, seed=n * 7 + dim)
     Q = orc.synth_queries(b, dim, seed=dim + b)
-    Qp = np.stack([orc.bf16_round(orc.prepare_query(q)) for q in Q])
+    Qp = device_prepared_queries(Q)
     ids, sc = cb.search(Q, k, eta, pref)
     assert ids.shape == (b, k) and ids.min() >= 0 and ids.max() < n
-    check_batch(Eb, Qp, dewi32, ent32, k, eta, pref, "cosine", ids, sc, max_excluded_frac=1.0, **TOL)
+    check_batch(Eb, Qp, dewi32, ent32, k, eta, pref, "cosine", ids, sc, min_decisive_frac=0.7, **TOL)

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import dewi_oracle as orc
-from parity import compare_query
+from parity import compare_query, device_prepared_queries
 
 pytestmark = pytest.mark.gpu
 
@@ -89,3 +89,83 @@ def test_c3_bf16_batched_properties(corpus_1m):
     # ... and a batch of 8 takes the matrix-core path too: same answers as inside the batch of 256
     ids_8, sc_8 = cb.search_device(Qb[:8].contiguous(), k, eta, 0.0)
     assert torch.equal(ids_8, ids[:8]) and torch.equal(sc_8, sc[:8])
+    # THE ORACLE at full size: 16 queries of the batch (every 16th, so all eight query-owning waves are
+    # covered) against search_prepared on the bf16-rounded corpus and the device-prepared queries — ids
+    # compared exactly wherever the f64 decision gaps exceed 1e-6, scores to 1e-5 (tests/parity.py)
+    Eb = cb.emb.float().cpu().numpy()
+    sel = list(range(0, 256, 16))
+    Qp = device_prepared_queries(Qb[sel].cpu().numpy())
+    ih, sh_ = ids.cpu().numpy(), sc.cpu().numpy()
+    n_dec = 0
+    for t, j in enumerate(sel):
+        decisive, msg = compare_query(Eb, Qp[t], dewi32, ent32, k, eta, 0.0, "cosine", ih[j], sh_[j], exact_gaps=False,
+                                      gap=1e-6, score_tol=1e-5, prepared=True)
+        assert msg is None, (j, msg)
+        n_dec += int(decisive)
+    assert n_dec >= 12, n_dec            # k = 100 leaves ~10 % of queries with an adjacent gap under 1e-6
+
+
+def test_c5_row_cosine_full_size():
+    """Config C5's I_hat kernel (row_cosine_512_kernel) at its full size, 1M x 512 x 2 matrices, against
+    torch's CPU F.cosine_similarity (the reference's own call, signals/cross_modal.py:69)."""
+    import torch
+    from dewi import signals
+    n, d = 1_000_000, 512
+    g = torch.Generator(device="cuda")
+    g.manual_seed(42)
+    A = torch.randn((n, d), generator=g, device="cuda")
+    g.manual_seed(43)
+    B = torch.randn((n, d), generator=g, device="cuda")
+    B[::7] = A[::7] * 0.5 + B[::7] * 0.05          # a share of strongly aligned pairs, not only ~0 cosines
+    A[123] = 0                                      # zero row: eps clamp, as torch
+    got = signals.cross_modal_similarity(A, B)
+    got = got.cpu().numpy() if hasattr(got, "cpu") else np.asarray(got)
+    want = torch.nn.functional.cosine_similarity(A.cpu(), B.cpu()).numpy()
+    assert got.shape == (n,)
+    assert np.max(np.abs(got - want)) <= 2e-6
+    assert got[123] == 0.0
+
+
+def test_c4_eight_shards_on_one_gpu():
+    """BASELINE configs[3] replayed on ONE GPU: eight resident 1M x 768 fp32 shards (24.6 GB), each scanned by
+    dewi_knn_candidates with its id_offset, records stacked and merged by dewi_merge_rerank — the whole
+    exchange minus the wire.  Must equal (i) ONE search over the 8M-row matrix bit for bit and (ii) the oracle
+    on 8 queries.  Multi-GPU proper (RCCL with > 1 rank) is NOT measured by this test."""
+    import torch
+    from dewi import _engine as eng
+    from dewi import _native as nat
+    S, n, d, k, eta = 8, 1_000_000, 768, 10, 0.3
+    total = S * n
+    big = torch.empty((total, d), dtype=torch.float32, device="cuda")
+    for s in range(S):                               # seeds 42..49 (SURVEY §8(d))
+        g = torch.Generator(device="cuda")
+        g.manual_seed(42 + s)
+        for r0 in range(0, n, 250_000):
+            big[s * n + r0: s * n + r0 + 250_000] = torch.randn((250_000, d), generator=g, device="cuda")
+    nat.check(nat.load_library().dewi_normalize_rows_f32(nat.ptr(big), nat.ptr(big), total, d, nat.stream_ptr()))
+    cols = orc.synth_payload_columns(total, seed=42)
+    dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    dd, ee = torch.from_numpy(dewi32).cuda(), torch.from_numpy(ent32).cuda()
+    whole = eng.DeviceCorpus(big, dd, ee, "cosine")
+    shards = [eng.DeviceCorpus(big[s * n:(s + 1) * n], dd[s * n:(s + 1) * n], ee[s * n:(s + 1) * n], "cosine",
+                               id_offset=s * n) for s in range(S)]
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    Q = torch.randn((16, d), generator=g, device="cuda")
+    c = 2 * k
+    lists = torch.stack([sh.candidates_device(Q, c) for sh in shards])           # [8, 16, 20, 4]
+    recs = eng.records_to_numpy(lists)
+    for s in range(S):                                                           # global ids, in range per shard
+        assert recs["id"][s].min() >= s * n and recs["id"][s].max() < (s + 1) * n
+    ids, sc = eng.merge_rerank_device(lists, c, k, eta, 0.0)
+    ids_w, sc_w = whole.search_device(Q, k, eta, 0.0)
+    assert torch.equal(ids, ids_w) and torch.equal(sc, sc_w)
+    assert ids.max().item() >= n                                                 # answers do come from later shards
+    E = big.cpu().numpy()
+    Qh, ih, sh_ = Q.cpu().numpy(), ids.cpu().numpy(), sc.cpu().numpy()
+    n_dec = 0
+    for j in range(8):
+        decisive, msg = compare_query(E, Qh[j], dewi32, ent32, k, eta, 0.0, "cosine", ih[j], sh_[j], exact_gaps=False)
+        assert msg is None, (j, msg)
+        n_dec += int(decisive)
+    assert n_dec >= 6

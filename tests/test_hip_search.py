@@ -104,9 +104,9 @@ def test_g2_c1_10k_768_golden(golden):
     assert np.array_equal(ids1, ids[:8])
     E = orc.build_matrix(raw)
     dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
-    excluded = check_batch(E, Q, dewi32, ent32, k, eta, 0.0, "cosine", ids, sc)
+    n_decisive = check_batch(E, Q, dewi32, ent32, k, eta, 0.0, "cosine", ids, sc, min_decisive_frac=0.9)
     exact = sum(int(np.array_equal(ids[j], g["ids"][j])) for j in range(Q.shape[0]))
-    assert exact >= Q.shape[0] - excluded
+    assert exact >= n_decisive
     assert np.max(np.abs(sc[ids == g["ids"]] - g["scores"][ids == g["ids"]])) <= 1e-5
 
 
@@ -161,7 +161,7 @@ def test_dimension_sweep_vs_oracle(dim):
     dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
     for k, eta, pref in ((1, 0.3, 0.0), (10, 0.3, 0.0), (10, 0.7, -0.5), (100, 0.25, 0.3), (150, 0.5, 0.0)):
         ids, sc = c.search(Q, k, eta, pref)          # k=150 -> c=300 > 256: dense-key path
-        check_batch(E, Q, dewi32, ent32, k, eta, pref, "cosine", ids, sc, max_excluded_frac=0.4)
+        check_batch(E, Q, dewi32, ent32, k, eta, pref, "cosine", ids, sc, min_decisive_frac=0.8 if k <= 10 else 0.6)
 
 
 @pytest.mark.parametrize("dim", [16, 100, 768])
@@ -174,7 +174,7 @@ def test_l2_space_vs_oracle(dim):
     c = _corpus(raw, cols, "l2")
     dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
     ids, sc = c.search(Q, 10, 0.3, 0.0)
-    check_batch(raw, Q, dewi32, ent32, 10, 0.3, 0.0, "l2", ids, sc, max_excluded_frac=0.4)
+    check_batch(raw, Q, dewi32, ent32, 10, 0.3, 0.0, "l2", ids, sc, min_decisive_frac=0.8)
 
 
 def test_ties_prefer_lower_row_and_zero_query():
@@ -245,13 +245,17 @@ def test_large_k_global_memory_path(n, k):
     ids, sc = c.search(Q, k, 0.3, 0.1)
     assert ids.shape == (2, k)
     for j in range(2):
+        # with > 1000 results some adjacent pair is always closer than the gap, so the query is not "decisive":
+        # the near-tie rules of tests/parity.py compare the id SET (every returned row an admissible candidate
+        # carrying that row's score, no sure candidate left out), and positions must agree except at swaps
+        decisive, msg = compare_query(E, Q[j], dewi32, ent32, k, 0.3, 0.1, "cosine", ids[j], sc[j])
+        assert msg is None, (j, msg)
         ref_ids, ref_sc = orc.search(E, Q[j], dewi32, ent32, k, 0.3, 0.1)
-        assert sorted(ids[j].tolist()) == sorted(ref_ids.tolist()) or k < n      # k == N: every row exactly once
-        assert np.all(np.diff(sc[j]) <= 0)
-        # same score multiset (fp32 summation order aside) and the same ids wherever scores are well separated
-        assert np.allclose(np.sort(sc[j]), np.sort(ref_sc), rtol=0, atol=1e-5)
-        agree = np.mean(ids[j] == ref_ids)
-        assert agree > 0.97, agree
+        if k == n:
+            assert sorted(ids[j].tolist()) == list(range(n))                     # every row exactly once
+        diff = set(ids[j].tolist()) ^ set(ref_ids.tolist())
+        assert len(diff) <= 4, diff                                               # only rows at the two decision boundaries
+        assert np.mean(ids[j] == ref_ids) > 0.99                                  # near-tie swaps only
 
 
 def test_pipelined_searcher_equals_serial_search():
@@ -336,7 +340,10 @@ def test_randomised_shapes_vs_oracle(case):
     dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
     ids, sc = c.search(Q, k, eta, pref)
     assert ids.shape == (b, k) and sc.shape == (b, k) and ids.min() >= 0 and ids.max() < n
-    check_batch(E, Q, dewi32, ent32, k, eta, pref, space, ids, sc, max_excluded_frac=1.0)
+    # decisive floor calibrated on the oracle alone (scripts/calibrate_parity_floors.py): 177 of the 185 queries
+    # of this sweep are decisive; the two low cases are (17 rows, dim 1: sims are +-1, all ties) and k > 200
+    floor = 0.3 if (dim == 1 or k > 200) else 0.75
+    check_batch(E, Q, dewi32, ent32, k, eta, pref, space, ids, sc, min_decisive_frac=floor)
 
 
 @pytest.mark.parametrize("space", ["cosine", "l2"])
@@ -358,4 +365,4 @@ def test_eight_queries_per_pass(dim, space):
         assert np.array_equal(i1[0], ids[j]) and np.array_equal(s1[0], sc[j]), j
     E = c.emb.cpu().numpy()
     dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
-    check_batch(E, Q, dewi32, ent32, 10, 0.3, 0.1, space, ids, sc, max_excluded_frac=0.4)
+    check_batch(E, Q, dewi32, ent32, 10, 0.3, 0.1, space, ids, sc, min_decisive_frac=0.9)

@@ -232,3 +232,121 @@ def test_two_bf16_shards_batched_path_equal_single_device(duplicates):
         assert ret[1]["marker"][0] == -2 and ret[1]["marker"][1] >= 0     # shard 1 overflowed on query 5 only
         assert ret[0]["marker"][0] >= 0                                   # shard 0 answered it
         assert ids[5, 0] == 7 or ids[5, 0] >= 100_000                    # the duplicated document wins
+
+
+# ---- CPU: world 8 with config C4's id arithmetic (1M rows per shard, offsets up to 7M) ------------
+_C4 = dict(world=8, rows_per_shard=1_000_000, real_per_shard=300, dim=24, b=4)
+
+
+def _c4_inputs():
+    """A sparse stand-in for the 8M-row corpus: each shard OWNS 1M doc ids but only 300 of them exist as real
+    rows, at local positions j * 3331 (so global ids run up to 7 996 069): the sharded searcher's offsets,
+    sizes, padding and int32 record ids are exercised at C4's scale without 8M x d of data."""
+    import dewi_oracle as orc
+    w, rps, real, d = _C4["world"], _C4["rows_per_shard"], _C4["real_per_shard"], _C4["dim"]
+    raw = orc.synth_corpus(w * real, d, seed=77)
+    cols = orc.synth_payload_columns(w * real, seed=77)
+    Q = orc.synth_queries(_C4["b"], d, seed=78)
+    local_pos = np.arange(real) * 3331
+    gids = np.concatenate([s * rps + local_pos for s in range(w)]).astype(np.int64)
+    return raw, cols, Q, gids
+
+
+def _c4_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import dewi_oracle as orc
+        from dewi.sharded import ShardedSearcher
+        raw, cols, Q, gids = _c4_inputs()
+        E = orc.build_matrix(raw)
+        dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+        real, rps = _C4["real_per_shard"], _C4["rows_per_shard"]
+        lo, hi = rank * real, (rank + 1) * real
+
+        def scan(queries, c):
+            out = np.zeros((len(queries), c, 4), np.int32)
+            out[..., 0] = np.float32(-np.inf).view(np.int32)
+            out[..., 3] = -1
+            for b, q in enumerate(queries):
+                s = orc.similarities(E, orc.prepare_query(q))[lo:hi]
+                order = np.lexsort((np.arange(len(s)), -s.astype(np.float64)))[:c]
+                out[b, : len(order)] = _pack(s[order], dewi32[lo:hi][order], ent32[lo:hi][order], gids[lo:hi][order])
+            return torch.from_numpy(out)
+
+        class Local:
+            id_offset = rank * rps
+            device = torch.device("cpu")
+        s = ShardedSearcher(Local(), rps, scan_fn=scan, merge_fn=_oracle_merge)
+        assert s.n_total == world * rps and s.id_offset == rank * rps and s.sizes == [rps] * world
+        ret[rank] = {k: s.search(Q, k, 0.3, 0.1) for k in (10, 100)}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world8_c4_id_arithmetic_on_cpu_gloo():
+    import dewi_oracle as orc
+    world = _C4["world"]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_c4_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    raw, cols, Q, gids = _c4_inputs()
+    E = orc.build_matrix(raw)
+    dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    assert len(ret) == world
+    for k in (10, 100):
+        ids0, sc0 = ret[0][k]
+        for r in range(1, world):
+            assert np.array_equal(ret[r][k][0], ids0) and np.array_equal(ret[r][k][1], sc0)
+        assert ids0.max() >= 7_000_000 or k == 10        # ids are global: some answers come from the last shard
+        for b in range(Q.shape[0]):
+            ids, sc = orc.search(E, Q[b], dewi32, ent32, k, 0.3, 0.1)
+            assert np.array_equal(ids0[b], gids[ids]), (k, b)            # dense row -> sparse global id
+            assert np.array_equal(sc0[b], sc), (k, b)
+
+
+# ---- GPU: the RCCL branch itself (all_gather_into_tensor / all_reduce on device tensors), world 1 ---------
+def _nccl_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+    try:
+        import dewi_oracle as orc
+        from dewi import _engine as eng
+        from dewi.sharded import HipFitSteps, ShardedRobustFit, ShardedSearcher
+        n, d = 30_000, 768
+        raw = orc.synth_corpus(n, d, seed=51)
+        cols = orc.synth_payload_columns(n, seed=51)
+        Q = orc.synth_queries(6, d, seed=52)
+        local = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+        s = ShardedSearcher(local, local.n_rows, always_collective=True)
+        assert s.backend == "nccl" and s.always_collective
+        out = {"search": {k: s.search(Q, k, 0.3, 0.2) for k in (10, 25)}}
+        out["plain"] = {k: local.search(Q, k, 0.3, 0.2) for k in (10, 25)}
+        # sharded robust fit through RCCL all-reduces of the device histograms
+        sig = np.stack([cols[key] for key in orc.SIGNAL_KEYS]).astype(np.float32)
+        steps = HipFitSteps(torch.from_numpy(sig).cuda())
+        med, mad = ShardedRobustFit(steps, n, always_collective=True).fit()
+        out["fit"] = (med, mad)
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_nccl_branch_world1_equals_single_device():
+    """The RCCL code path (ShardedSearcher.exchange's all_gather_into_tensor on device records, the sharded fit's
+    all_reduce of device histograms) executed for real in a fresh child process — with ONE rank, which is all a
+    one-GPU box allows: multi-GPU remains unmeasured on hardware."""
+    import dewi_oracle as orc
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_nccl_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
+    out = ret[0]
+    for k in (10, 25):
+        assert np.array_equal(out["search"][k][0], out["plain"][k][0])
+        assert np.array_equal(out["search"][k][1], out["plain"][k][1])
+    cols = orc.synth_payload_columns(30_000, seed=51)
+    med, mad = orc.robust_fit({key: cols[key].astype(np.float32) for key in orc.SIGNAL_KEYS})
+    for j, key in enumerate(orc.SIGNAL_KEYS):
+        assert float(np.float64(out["fit"][0][j])) == med[key] and float(np.float64(out["fit"][1][j])) == mad[key]
