@@ -294,9 +294,9 @@ def run_c2(args, torch, dist, eng, nat, rank, world, device):
 
     run(0, args.warmup)
     barrier()
-    # hipEvents around the scan kernel inside the timed region: every scan of a short run (the driver's 20
-    # steps), every 8th of a long one (the two event records cost ~5 us of stream time each)
-    eng.timing(1 if args.steps < MIN_ROOFLINE_LAUNCHES else 8)
+    # hipEvents around every 8th scan kernel inside the timed region (the two event records cost ~5-10 us of
+    # stream time, so the timed region is only sampled; the roofline leg below brackets every launch)
+    eng.timing(8)
     t0 = time.perf_counter()
     run(args.warmup, args.steps)
     barrier()
@@ -542,7 +542,7 @@ def run_c3(args, torch, eng, nat, device):
 
     run(0, args.warmup)
     torch.cuda.synchronize()
-    eng.timing(1 if args.steps < MIN_ROOFLINE_LAUNCHES else 4)
+    eng.timing(4)
     t0 = time.perf_counter()
     run(args.warmup, args.steps)
     torch.cuda.synchronize()
@@ -661,7 +661,7 @@ def run_c4(args, torch, eng, nat, device):
 
     run(0, args.warmup)
     torch.cuda.synchronize()
-    eng.timing(1 if args.steps * S < 4 * MIN_ROOFLINE_LAUNCHES else 4)
+    eng.timing(8)
     t0 = time.perf_counter()
     run(args.warmup, args.steps)
     torch.cuda.synchronize()

@@ -169,10 +169,12 @@ def test_scorer_row_api_serves_the_fitted_table():
     assert sc.score(rows[777]) == got[777] and sc.score(rows[5]) == got[5]
     clone = dict(rows[777])
     assert sc.score(clone) == got[777]                            # single-document launch: same bits
-    rows[10]["noise"] += 0.25                                     # edited after the fit: must not come from the cache
-    fresh = sc.score(rows[10])
-    assert fresh != got[10]
-    assert fresh == sc.score(dict(rows[10]))
+    e = int(np.argmin(np.abs(got - 0.5)))                         # a row in the middle of the sigmoid (not clipped)
+    rows[e]["noise"] += 0.25                                      # edited after the fit: must not come from the cache
+    fresh = sc.score(rows[e])
+    assert fresh != got[e]
+    assert fresh == sc.score(dict(rows[e]))
     # changing the weights invalidates the cached column
+    m = int(np.argsort(np.abs(got - 0.5))[1])                     # another unclipped row
     sc.weights.alpha_n = 2.0
-    assert sc.score(rows[3]) == sc.score(dict(rows[3])) != got[3]
+    assert sc.score(rows[m]) == sc.score(dict(rows[m])) != got[m]
