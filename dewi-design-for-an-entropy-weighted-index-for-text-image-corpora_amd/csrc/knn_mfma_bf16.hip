@@ -65,6 +65,7 @@ namespace dewi {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4m __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 #ifndef DEWI_MFMA_QB
 #define DEWI_MFMA_QB 1   // 32-query blocks per wave: 1 -> 8 waves (two per SIMD, 256 registers each), 2 -> 4 waves
@@ -137,8 +138,8 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
     const uint16_t* __restrict__ E, int64_t n_rows, const uint16_t* __restrict__ Qb, int64_t n_tiles,
     int64_t tile_stride, const float* __restrict__ thr, uint64_t* __restrict__ out, int64_t out_stride,
     uint32_t* __restrict__ cnt, int n_active) {
-  // DENSE: `out` is a float array: out[q * out_stride + sample position] = score of every document of the
-  //        (strided) tiles.
+  // DENSE (the sample pass): `out` is a float array: out[q * out_stride + (2*blockIdx.x + h) * 16 + j] = the best
+  //        score register j of that lane saw over this workgroup's (strided) tiles — 32 group maxima per workgroup.
   // filter: raw records out[((2*blockIdx.x + h) * 256 + q) * out_stride + slot], cnt[(2*blockIdx.x + h) * 256 + q].
 #if defined(__HIP_DEVICE_COMPILE__)  // the body holds gfx950 inline asm: the host pass only needs the launch stub
   constexpr int DIM = KS * 16;
@@ -259,6 +260,19 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
   uint64_t* const out_uniform = reinterpret_cast<uint64_t*>(
       (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(out_bits >> 32)))) << 32) |
       static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(out_bits))));
+  // Sample pass (DENSE): instead of writing every score (256 x 31 K scattered 4-byte stores per pass, and as many
+  // values for the threshold kernel to read back) each lane keeps, per accumulator register, the MAXIMUM over the
+  // tiles of this workgroup.  The c-th largest of those group maxima (gridDim x 2 halves x 16 registers = 8192
+  // groups per query) is a lower bound of the query's final c-th best score, as the c-th best sample score was —
+  // c different documents reach it — and with 8192 groups >> c it is within ~1 % of that bound's survivor rate.
+  float mx[DENSE ? kQB : 1][16];
+  if constexpr (DENSE) {
+#pragma unroll
+    for (int b = 0; b < kQB; ++b) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) mx[b][j] = -__builtin_inff();
+    }
+  }
   // The epilogue of tile i: D[doc = (j&3) + 8*(j>>2) + 4*h][query = 32*wave + r].
   auto epilogue = [&](f32x16 (&acc)[kQB], int64_t i) {
     const int64_t row0 = i * tile_stride * kTileRows;
@@ -276,11 +290,10 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
       if (DEWI_MFMA_ABLATE == 1) {
         asm volatile("" ::"v"(acc[b]));
       } else if constexpr (DENSE) {
-        // sample pass: plain fp32 scores (rows past the corpus end were set to -inf above)
-        float* dense = reinterpret_cast<float*>(out) + static_cast<int64_t>(32 * kQB * wave + 32 * b + r) * out_stride +
-                       i * kTileRows + 4 * h;
+        // sample pass: every accumulator register keeps the best score it has seen (rows past the corpus end were
+        // set to -inf above; fmax ignores NaN, which can only make the bound lower, never invalid)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) dense[(j & 3) + 8 * (j >> 2)] = acc[b][j];
+        for (int j = 0; j < 16; ++j) mx[b][j] = __builtin_fmaxf(mx[b][j], acc[b][j]);
       } else {
         // Filtering a lane's 16 scores.  What this costs is NOT the compares: vector ALU work of the
         // filtering wave issues in the gaps of the partner wave's MFMAs (an MFMA holds the SIMD's vector
@@ -499,6 +512,16 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
       const uint32_t seg_q = (static_cast<uint32_t>(blockIdx.x) * 2 + h) * kQueriesPerPass + (32 * kQB * wave + 32 * b + r);
       cnt[seg_q] = (off[b] >> 3) - seg_q * static_cast<uint32_t>(out_stride);
     }
+  } else if (active) {
+    // group maxima of this lane: 16 consecutive floats (64 B) of the query's row
+#pragma unroll
+    for (int b = 0; b < kQB; ++b) {
+      f32x4v* dst = reinterpret_cast<f32x4v*>(reinterpret_cast<float*>(out) +
+                                              static_cast<int64_t>(32 * kQB * wave + 32 * b + r) * out_stride +
+                                              (static_cast<int64_t>(blockIdx.x) * 2 + h) * 16);
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4) dst[j4] = f32x4v{mx[b][4 * j4], mx[b][4 * j4 + 1], mx[b][4 * j4 + 2], mx[b][4 * j4 + 3]};
+    }
   }
 #endif
 }
@@ -618,7 +641,9 @@ MfmaLayout plan_mfma(int64_t n_rows, int dim, int n_queries, int n_candidates, i
   m.q_pad = m.groups * kQueriesPerPass;
   m.n_tiles = (n_rows + kTileRows - 1) / kTileRows;
   m.n_sample_tiles = (m.n_tiles + kSampleStride - 1) / kSampleStride;
-  m.sample_stride = static_cast<int64_t>(m.n_sample_tiles) * kTileRows;
+  // group maxima per query: sample workgroups x 2 lane halves x 16 accumulator registers
+  const int64_t sample_blocks = m.n_sample_tiles < compute_units ? m.n_sample_tiles : compute_units;
+  m.sample_stride = sample_blocks * 32;
   // Filter pass: one workgroup per CU; every (workgroup, lane half, query) has a private half-segment.
   // Expected survivors per query ~ n_rows * c / n_sample = 32 c, spread evenly over the half-segments;
   // 4x head-room, at least 32 records.

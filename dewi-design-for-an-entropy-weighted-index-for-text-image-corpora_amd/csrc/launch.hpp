@@ -97,7 +97,7 @@ struct MfmaLayout {
   int q_pad;               // groups * 256
   int64_t n_tiles;         // 32-row tiles
   int64_t n_sample_tiles;  // every 32nd tile
-  int64_t sample_stride;   // dense sample keys per query (n_sample_tiles * 32)
+  int64_t sample_stride;   // group maxima per query the sample pass emits (sample workgroups * 32)
   int n_blocks;            // workgroups of the filter pass
   int n_seg;               // candidate half-segments per query (2 per workgroup)
   int seg_cap;             // records per half-segment
