@@ -244,6 +244,26 @@ int knn_rerank_impl(const void* d_E, int elem_type, int64_t n_rows, int dim, con
     if (e != hipSuccess) return hip_fail(e, "select_rerank launch");
     return DEWI_OK;
   }
+  if (elem_type == 0 && g_tuning.mfma != 0 && dewi::mfma_f32_path_supported(n_rows, dim, n_queries, c, space)) {
+    // 5+ queries over an fp32 corpus: matrix-core path, one corpus pass per 32 queries
+    const dewi::MfmaF32Layout M = dewi::plan_mfma_f32(n_rows, dim, n_queries, c, dev.cus);
+    if (!d_ws || ws_bytes < M.total) return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, M.total);
+    hipError_t e = dewi::launch_mfma_f32(M, static_cast<const float*>(d_E), n_rows, dim, d_Q, n_queries, c, space, ws, stream);
+    if (e != hipSuccess) return hip_fail(e, "fp32 mfma scan launch");
+    const dewi::RerankParams rp = make_rerank(eta, pref, transform, space);
+    for (int g = 0; g < M.groups; ++g) {
+      const int q0 = g * 32;
+      const int nq = n_queries - q0 < 32 ? n_queries - q0 : 32;
+      const dewi::SegmentLayout seg{M.n_seg, M.seg_cap, 1, static_cast<int64_t>(32) * M.seg_cap, 32, 8192};
+      const uint64_t* keys = reinterpret_cast<const uint64_t*>(ws + M.cand_off) + static_cast<int64_t>(g) * M.n_seg * 32 * M.seg_cap;
+      const uint32_t* counts = reinterpret_cast<const uint32_t*>(ws + M.cnt_off) + static_cast<int64_t>(g) * M.n_seg * 32;
+      e = dewi::launch_select_rerank(keys, 0, 0, nq, c, k, rp, d_dewi32, d_ent32, 0, d_out_ids + static_cast<int64_t>(q0) * k,
+                                     d_out_scores + static_cast<int64_t>(q0) * k, nullptr, counts, seg, stream);
+      if (e != hipSuccess) break;
+    }
+    if (e != hipSuccess) return hip_fail(e, "select_rerank launch");
+    return DEWI_OK;
+  }
   const KnnLayout L = layout_knn(n_rows, dim, elem_type ? 2 : 4, n_queries, c, dev.cus);
   if (!d_ws || ws_bytes < L.total) return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, L.total);
   rc = run_scan(L, d_E, elem_type, n_rows, dim, d_Q, n_queries, c, space, ws, stream);
@@ -327,7 +347,11 @@ size_t dewi_knn_workspace_bytes(int64_t n_rows, int dim, int n_queries, int n_ca
     const size_t m = dewi::plan_mfma(n_rows, dim, n_queries, n_candidates, dev.cus).total;
     if (m > a) a = m;
   }
-  return a;  // valid for either element type and either bf16 path
+  if (dewi::mfma_f32_path_supported(n_rows, dim, n_queries, n_candidates, DEWI_SPACE_COSINE)) {
+    const size_t m = dewi::plan_mfma_f32(n_rows, dim, n_queries, n_candidates, dev.cus).total;
+    if (m > a) a = m;
+  }
+  return a;  // valid for either element type and every path (small-batch scans, bf16 / fp32 matrix-core)
 }
 
 int dewi_knn_rerank_f32(const float* d_E, int64_t n_rows, int dim, const float* d_Q, int n_queries,
@@ -453,6 +477,30 @@ int dewi_knn_candidates(const void* d_E, int elem_type, int64_t n_rows, int dim,
       const uint64_t* keys = reinterpret_cast<const uint64_t*>(wsm + M.cand_off) +
                              static_cast<int64_t>(g) * M.n_seg * 256 * M.seg_cap;
       const uint32_t* counts = reinterpret_cast<const uint32_t*>(wsm + M.cnt_off) + static_cast<int64_t>(g) * M.n_seg * 256;
+      e = dewi::launch_select_rerank(keys, 0, 0, nq, n_candidates, 0, rp0, d_dewi32, d_ent32, id_offset, nullptr, nullptr,
+                                     d_out + static_cast<int64_t>(q0) * n_candidates, counts, seg, stream);
+      if (e != hipSuccess) break;
+    }
+    if (e != hipSuccess) return hip_fail(e, "select (candidates) launch");
+    return DEWI_OK;
+  }
+  if (elem_type == 0 && g_tuning.mfma != 0 && c_local == n_candidates &&
+      dewi::mfma_f32_path_supported(n_rows, dim, n_queries, n_candidates, space)) {
+    // 5+ queries over an fp32 shard: matrix-core path; an overflowed query's records carry id -2
+    const dewi::MfmaF32Layout M = dewi::plan_mfma_f32(n_rows, dim, n_queries, n_candidates, dev.cus);
+    if (!d_workspace || workspace_bytes < M.total)
+      return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, M.total);
+    char* wsm = static_cast<char*>(d_workspace);
+    hipError_t e = dewi::launch_mfma_f32(M, static_cast<const float*>(d_E), n_rows, dim, d_Q, n_queries, n_candidates, space,
+                                         wsm, stream);
+    if (e != hipSuccess) return hip_fail(e, "fp32 mfma scan launch");
+    const dewi::RerankParams rp0 = make_rerank(0.0, 0.0);
+    for (int g = 0; g < M.groups; ++g) {
+      const int q0 = g * 32;
+      const int nq = n_queries - q0 < 32 ? n_queries - q0 : 32;
+      const dewi::SegmentLayout seg{M.n_seg, M.seg_cap, 1, static_cast<int64_t>(32) * M.seg_cap, 32, 8192};
+      const uint64_t* keys = reinterpret_cast<const uint64_t*>(wsm + M.cand_off) + static_cast<int64_t>(g) * M.n_seg * 32 * M.seg_cap;
+      const uint32_t* counts = reinterpret_cast<const uint32_t*>(wsm + M.cnt_off) + static_cast<int64_t>(g) * M.n_seg * 32;
       e = dewi::launch_select_rerank(keys, 0, 0, nq, n_candidates, 0, rp0, d_dewi32, d_ent32, id_offset, nullptr, nullptr,
                                      d_out + static_cast<int64_t>(q0) * n_candidates, counts, seg, stream);
       if (e != hipSuccess) break;

@@ -661,6 +661,25 @@ MfmaLayout plan_mfma(int64_t n_rows, int dim, int n_queries, int n_candidates, i
   return m;
 }
 
+// Thresholds of `n_queries` queries from their sample values (dense [n_queries][stride], n_sample valid
+// per query): shared by the bf16 and the fp32 matrix-core paths.
+hipError_t launch_sample_threshold(const float* dense, int64_t n_sample, int64_t stride, int n_candidates, float* thr,
+                                   int n_queries, hipStream_t stream) {
+  static PerDeviceOnce once;
+  const hipError_t e = once.run([] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&sample_threshold_kernel<true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kMaxStagedSample * 4);
+  });
+  if (e != hipSuccess) return e;
+  if (n_sample <= kMaxStagedSample)
+    hipLaunchKernelGGL(sample_threshold_kernel<true>, dim3(n_queries), dim3(kSelectThreads),
+                       static_cast<size_t>(n_sample) * 4, stream, dense, n_sample, stride, n_candidates, thr);
+  else
+    hipLaunchKernelGGL(sample_threshold_kernel<false>, dim3(n_queries), dim3(kSelectThreads), 0, stream, dense, n_sample,
+                       stride, n_candidates, thr);
+  return hipGetLastError();
+}
+
 template <int KS>
 static hipError_t run_mfma_dim(const MfmaLayout& m, const uint16_t* E, int64_t n_rows, int n_queries, int n_candidates,
                                char* ws, int compute_units, hipStream_t stream) {
@@ -671,11 +690,8 @@ static hipError_t run_mfma_dim(const MfmaLayout& m, const uint16_t* E, int64_t n
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan_bf16<KS, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan_bf16<KS, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&sample_threshold_kernel<true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kMaxStagedSample * 4);
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan_bf16<KS, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   });
   if (ea != hipSuccess) return ea;
   const uint16_t* qb = reinterpret_cast<const uint16_t*>(ws + m.qb_off);
@@ -696,13 +712,8 @@ static hipError_t run_mfma_dim(const MfmaLayout& m, const uint16_t* E, int64_t n
                        reinterpret_cast<uint64_t*>(dense), m.sample_stride, static_cast<uint32_t*>(nullptr), n_active);
     // 2. per-query threshold (real queries only: a padding query's sample scores are all equal, which is the
     //    worst case of the histogram select, and its threshold is not used)
-    if (m.sample_stride <= kMaxStagedSample)
-      hipLaunchKernelGGL(sample_threshold_kernel<true>, dim3(n_active), dim3(kSelectThreads),
-                         static_cast<size_t>(m.sample_stride) * 4, stream, dense, m.sample_stride, m.sample_stride,
-                         n_candidates, tg);
-    else
-      hipLaunchKernelGGL(sample_threshold_kernel<false>, dim3(n_active), dim3(kSelectThreads), 0, stream, dense,
-                         m.sample_stride, m.sample_stride, n_candidates, tg);
+    const hipError_t et = launch_sample_threshold(dense, m.sample_stride, m.sample_stride, n_candidates, tg, n_active, stream);
+    if (et != hipSuccess) return et;
     // 3. full pass with the filter: n_blocks workgroups, each writing its own half-segments and counts
     //    (the kernel dewi_timing_read reports: algorithmic bytes = n_rows * dim * 2 per launch)
     timing_begin(stream);

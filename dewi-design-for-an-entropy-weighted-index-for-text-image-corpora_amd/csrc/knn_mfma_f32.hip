@@ -1,0 +1,372 @@
+// Batched kNN over an fp32 corpus on the matrix cores: 5..32 queries per corpus pass at (close to)
+// the HBM rate, gfx950 (MI355X).
+//
+// Same contract as the scan kernels — steps 1-3 of ExactIndex.search (reference
+// src/dewi/backends.py:420-444) on the reference's native dtype (fp32 rows, backends.py:403) — for
+// query batches: `search_batch` on an fp32 corpus was vector-ALU-bound (8 queries per pass 0.68 ms at
+// 1M x 768); v_mfma_f32_32x32x2_f32 computes a 32-document x 32-query block at the fp32 vector rate
+// with EXACT fp32 products and fp32 accumulation (an fmaf chain, bit for bit), so 32 queries cost one
+// corpus pass.
+//
+// Roofline: co-limited.  Algorithmic bytes per pass = n_rows * dim * 4 (HBM, the corpus read once);
+// flops = 2 * 32 * n_rows * dim (49 GFLOP at 1M x 768) at the 157 TFLOP/s fp32 matrix peak = 0.31 ms
+// against 0.38 ms at 8 TB/s.
+//
+// Structure (one 8-wave workgroup per CU, persistent over 32-document tiles):
+//  * A tile is cut into CHUNKS of 32 rows x 256 columns (32 KiB): 32 DMA pieces of 1 KiB = one row's
+//    256 columns each (buffer_load_dwordx4 ... lds, global -> LDS without registers), ring of four
+//    chunks: one being multiplied, three in flight (96 KiB per CU).
+//  * THE EIGHT WAVES SPLIT THE DEPTH: wave w multiplies columns [32w, 32w+32) of every chunk, so its
+//    share of the 32 normalised queries is dim/8 columns = dim/16 registers per lane (48 at dim 768)
+//    and lives in registers for the whole kernel.  Per chunk and wave: 4 ds_read_b128 (lane (r, h)
+//    takes columns 32w + 8m + 4h .. +3 of row r, m = 0..3) and 16 MFMAs — MFMA 4m+i multiplies
+//    column 32w + 8m + 4h + i on both operands (the k index of an MFMA is only a pairing of A and B
+//    lanes, so any column may stand at any k as long as both sides agree).
+//  * BANK CONFLICTS: chunk rows are 1 KiB apart, so the 16 lanes of a ds_read_b128 group (16 rows, same
+//    column unit) would all hit the same banks.  The LDS image is linear per piece and the SOURCE
+//    address is permuted: 16-byte unit u of row r is stored at unit u ^ (r & 15); reads apply the same
+//    XOR -> conflict-free.
+//  * At the end of a tile the eight partial 32 x 32 blocks are summed through LDS in a fixed order
+//    (wave 0 .. 7: bit-reproducible): wave w receives accumulator registers 2w and 2w+1 — two
+//    documents per lane — and filters them against the query's threshold.
+//  * THRESHOLDS AND SURVIVORS as in the bf16 matrix-core path (knn_mfma_bf16.hip): a sample pass of the
+//    same kernel over every `sample_stride`-th tile keeps group maxima, their c-th largest is a valid
+//    lower bound of the query's c-th best score; the full pass stores every score that is not below it
+//    as a raw record (row << 32 | score bits) into the (workgroup, query) segment — the slot comes
+//    from a per-query counter in LDS (survivors are rare here: ~0.1 per tile and workgroup) — and the
+//    select kernel finishes exactly.  A segment that overflows (adversarial corpora) marks the query
+//    (count > capacity): ids -1, the caller re-runs it on the exact small-batch kernels.
+#include "select_common.hpp"
+
+namespace dewi {
+
+typedef float f32x16f __attribute__((ext_vector_type(16)));
+typedef float f32x4f __attribute__((ext_vector_type(4)));
+
+constexpr int kF32Threads = 512;
+constexpr int kF32Waves = kF32Threads / kWave;       // 8: the depth split
+constexpr int kF32TileRows = 32;
+constexpr int kF32Queries = 32;                      // queries per pass (one MFMA column block)
+constexpr int kF32ChunkCols = 256;
+constexpr int kF32ChunkBytes = kF32TileRows * kF32ChunkCols * 4;   // 32 KiB
+constexpr int kF32Ring = 4;
+[[maybe_unused]] constexpr int kF32PiecesPerWave = kF32TileRows / kF32Waves;        // 4 rows (= 1 KiB pieces) per wave and chunk
+constexpr int kF32RedRegs = 14;                                     // partial registers a wave hands over (all but its own two)
+constexpr int kF32RedBytes = kF32Waves * kF32RedRegs * kWave * 4;   // 28 KiB
+constexpr int kF32LdsBytes = kF32Ring * kF32ChunkBytes + kF32RedBytes + kF32Queries * 4;
+#ifndef DEWI_F32MFMA_DMA_AUX
+#define DEWI_F32MFMA_DMA_AUX 2   // non-temporal tile DMA: the corpus is read once
+#endif
+
+using LdsPtrF = void __attribute__((address_space(3)))*;
+
+// CH = dim / 256 chunks per tile.  Tiles of this launch: t = (blockIdx.x + i * gridDim.x) * tile_stride.
+// SAMPLE: out is a float array [32][out_stride]: out[q * out_stride + (16 * blockIdx.x + 2 * wave + h) * 2 + e] =
+//         the best score this lane's register e saw over the workgroup's tiles (32 group maxima per workgroup).
+// filter: raw records out[(blockIdx.x * 32 + q) * out_stride + slot], cnt[blockIdx.x * 32 + q] = records offered.
+template <int CH, bool SAMPLE>
+__global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const float* __restrict__ E, int64_t n_rows,
+                                                                const float* __restrict__ Qn, int64_t n_tiles,
+                                                                int64_t tile_stride, const float* __restrict__ thr,
+                                                                uint64_t* __restrict__ out, int64_t out_stride,
+                                                                uint32_t* __restrict__ cnt, int n_active) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int DIM = CH * kF32ChunkCols;
+  extern __shared__ __attribute__((aligned(16))) char lds[];   // ring | partial sums | per-query counters
+  float* const red = reinterpret_cast<float*>(lds + kF32Ring * kF32ChunkBytes);
+  uint32_t* const lcnt = reinterpret_cast<uint32_t*>(lds + kF32Ring * kF32ChunkBytes + kF32RedBytes);
+
+  const int lane = lane_id();
+  const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  const int r = lane & 31, h = lane >> 5;
+
+  // ---- this wave's share of the queries (B operand): lane (r, h) holds Qn[r][256 ch + 32 w + 8 m + 4 h .. +3]
+  f32x4f qf[CH][4];
+#pragma unroll
+  for (int ch = 0; ch < CH; ++ch) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      qf[ch][m] = *reinterpret_cast<const f32x4f*>(Qn + static_cast<int64_t>(r) * DIM + kF32ChunkCols * ch + 32 * w + 8 * m + 4 * h);
+  }
+  const float thr_l = SAMPLE ? -__builtin_inff() : (r < n_active ? thr[r] : __builtin_inff());
+  // pin the waits for these loads here, before any DMA is in flight (a compiler-inserted vmcnt(0) inside the
+  // chunk loop would drain the ring on every iteration)
+#pragma unroll
+  for (int ch = 0; ch < CH; ++ch) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) asm volatile("" ::"v"(qf[ch][m]));
+  }
+  asm volatile("" ::"v"(thr_l));
+  if (!SAMPLE && threadIdx.x < kF32Queries) lcnt[threadIdx.x] = 0;   // read first at a tile end, behind several barriers
+
+  // ---- DMA: piece p of a chunk (p = 0..3) is row w + 8 p; its 16-byte unit u lands at LDS unit u ^ (row & 15),
+  // i.e. lane l (LDS unit l) fetches unit l ^ (row & 15).  row & 15 is w for p even and w + 8 for p odd.
+  const uint32_t row_bytes = DIM * 4;
+  const uint32_t voff_even = static_cast<uint32_t>(w) * row_bytes + 16u * static_cast<uint32_t>(lane ^ w);
+  const uint32_t voff_odd = static_cast<uint32_t>(w) * row_bytes + 16u * static_cast<uint32_t>(lane ^ (w + 8));
+  const char* Eb = reinterpret_cast<const char*>(E);
+  const int64_t first = static_cast<int64_t>(blockIdx.x), step = static_cast<int64_t>(gridDim.x);
+  const int64_t n_my = first < n_tiles ? (n_tiles - first + step - 1) / step : 0;
+  // descriptor of this workgroup's it-th tile: base = the tile's first row, size = its valid bytes, so rows past
+  // the end of the corpus — and whole tiles past this workgroup's last one (size 0) — read as zeros
+  auto tile_rsrc = [&](int64_t it) {
+    int64_t row0 = 0;
+    int valid = 0;
+    if (it < n_my) {
+      row0 = (first + it * step) * tile_stride * kF32TileRows;
+      const int64_t left = n_rows - row0;
+      valid = left < kF32TileRows ? static_cast<int>(left) : kF32TileRows;
+    }
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Eb + row0 * row_bytes), 0, valid * static_cast<int>(row_bytes),
+                                             0x00020000);
+  };
+  auto issue_chunk = [&](__amdgpu_buffer_rsrc_t rsrc, int ch, int slot) {
+    char* base = lds + slot * kF32ChunkBytes + w * 1024;
+#pragma unroll
+    for (int p = 0; p < kF32PiecesPerWave; ++p)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtrF)(base + p * 8 * 1024), 16, (p & 1) ? voff_odd : voff_even,
+                                               p * 8 * static_cast<int>(row_bytes) + ch * 1024, 0, DEWI_F32MFMA_DMA_AUX);
+  };
+  // ---- A-fragment read addresses inside ring slot 0: row r, unit (8 w + 2 m + h) ^ (r & 15)
+  uint32_t a_addr[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+    a_addr[m] = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((LdsPtrF)(lds))) +
+                static_cast<uint32_t>(r * 1024 + 16 * ((8 * w + 2 * m + h) ^ (r & 15)));
+
+  // chunk sequence of this workgroup: g = it * CH + ch -> ring slot g & 3.  Chunks g+1 .. g+3 are in flight while
+  // chunk g is multiplied; chunks past the last tile are fetched through an empty descriptor (zeros, no memory
+  // traffic) so that the count of outstanding pieces — and with it every vmcnt below — is the same on every
+  // iteration.
+  auto issue_g = [&](int64_t g) {
+    const int64_t it = g / CH;
+    const int ch = static_cast<int>(g - it * CH);
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(it);
+    const int slot = static_cast<int>(g & 3);
+    // ch is a run-time value here (prologue); the loop below calls issue_chunk with compile-time ch
+    switch (ch) {
+      case 0: issue_chunk(rs, 0, slot); break;
+      case 1: if constexpr (CH > 1) issue_chunk(rs, 1, slot); break;
+      case 2: if constexpr (CH > 2) issue_chunk(rs, 2, slot); break;
+      case 3: if constexpr (CH > 3) issue_chunk(rs, 3, slot); break;
+      case 4: if constexpr (CH > 4) issue_chunk(rs, 4, slot); break;
+      default: if constexpr (CH > 5) issue_chunk(rs, 5, slot); break;
+    }
+  };
+  if (n_my > 0) {
+    issue_g(0);
+    issue_g(1);
+    issue_g(2);
+  }
+
+  float mx0 = -__builtin_inff(), mx1 = -__builtin_inff();
+  f32x16f acc;
+  for (int64_t it = 0; it < n_my; ++it) {
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+      const int64_t g = it * CH + ch;
+      const int slot = static_cast<int>(g & 3);
+      // own pieces of chunk g have landed: of the 12 pieces this wave has outstanding (chunks g, g+1, g+2) all
+      // but the 8 youngest are done (vector-memory operations retire in issue order; a survivor store in between
+      // only makes the wait stricter)
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      // one barrier per chunk: every wave's pieces of chunk g are in LDS, and every wave has finished reading the
+      // slot of chunk g-1, which chunk g+3 now refills
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      issue_chunk(tile_rsrc(it + (ch + 3) / CH), (ch + 3) % CH, static_cast<int>((g + 3) & 3));
+      const uint32_t slot_off = static_cast<uint32_t>(slot) * kF32ChunkBytes;
+      f32x4f a[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        asm volatile("ds_read_b128 %0, %1" : "=v"(a[m]) : "v"(a_addr[m] + slot_off));
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        // LDS returns data in order: before fragment m is used at most the 3 - m younger reads may be pending
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a[m]) : "n"(3 - m));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f32x16f zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][i], qf[ch][m][i], (ch == 0 && m == 0 && i == 0) ? zero : acc, 0, 0, 0);
+        }
+      }
+    }
+    // ---- tile epilogue: sum the eight depth partials; wave w ends up with registers 2w and 2w+1 of the block
+    // D[doc = (j & 3) + 8 (j >> 2) + 4 h][query = r].  Partials of register j from wave v sit at
+    // red[(v * 14 + (j < 2v ? j : j - 2)) * 64 + lane] (a wave does not store the two registers it keeps).
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (j != 2 * w && j != 2 * w + 1) red[(w * kF32RedRegs + (j < 2 * w ? j : j - 2)) * kWave + lane] = acc[j];
+    }
+    float own0 = 0.f, own1 = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < kF32Waves; ++ww) {
+      if (w == ww) {
+        own0 = acc[2 * ww];
+        own1 = acc[2 * ww + 1];
+      }
+    }
+    // LDS stores are complete when lgkmcnt reaches 0 (not __syncthreads(): its release fence would also wait
+    // for vmcnt(0) and drain the DMA ring at every tile end)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int v = 0; v < kF32Waves; ++v) {     // fixed order 0..7 whichever wave does the sum
+      float p0, p1;
+      if (v == w) {
+        p0 = own0;
+        p1 = own1;
+      } else {
+        const int j0 = 2 * w, j1 = 2 * w + 1;
+        p0 = red[(v * kF32RedRegs + (j0 < 2 * v ? j0 : j0 - 2)) * kWave + lane];
+        p1 = red[(v * kF32RedRegs + (j1 < 2 * v ? j1 : j1 - 2)) * kWave + lane];
+      }
+      s0 = v == 0 ? p0 : s0 + p0;
+      s1 = v == 0 ? p1 : s1 + p1;
+    }
+    // (the next write to `red` is a whole tile — CH chunk barriers — away: no barrier needed behind these reads)
+    const int64_t row0 = (first + it * step) * tile_stride * kF32TileRows;
+    const int64_t doc = row0 + 2 * (w & 1) + 8 * (w >> 1) + 4 * h;     // register 2w; register 2w+1 is the next row
+    if (doc >= n_rows) s0 = -__builtin_inff();                         // padding rows of the last tile never pass
+    if (doc + 1 >= n_rows) s1 = -__builtin_inff();
+    if constexpr (SAMPLE) {
+      mx0 = __builtin_fmaxf(mx0, s0);
+      mx1 = __builtin_fmaxf(mx1, s1);
+    } else {
+      const bool pass0 = !(s0 < thr_l), pass1 = !(s1 < thr_l);         // NaN passes (NumPy ranks NaN first)
+      if (__builtin_amdgcn_ballot_w64(pass0 || pass1) != 0ull) {
+        const uint32_t cap = static_cast<uint32_t>(out_stride);
+        uint64_t* seg = out + (static_cast<int64_t>(blockIdx.x) * kF32Queries + r) * out_stride;
+        // the slot comes from the query's counter in LDS.  Inline asm: for a plain atomicAdd on LDS hipcc first
+        // waits for vmcnt(0) — every LDS-DMA piece in flight could alias the counter as far as it knows — which
+        // would drain this wave's ring (and stall the workgroup at the next barrier) on every survivor.
+        const uint32_t cnt_addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((LdsPtrF)(lcnt))) + 4u * static_cast<uint32_t>(r);
+        auto take_slot = [&]() {
+          uint32_t slot;
+          asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(slot) : "v"(cnt_addr), "v"(1u) : "memory");
+          return slot;
+        };
+        if (pass0) {
+          const uint32_t slot = take_slot();
+          if (slot < cap) seg[slot] = (static_cast<uint64_t>(static_cast<uint32_t>(doc)) << 32) | __float_as_uint(s0);
+        }
+        if (pass1) {
+          const uint32_t slot = take_slot();
+          if (slot < cap) seg[slot] = (static_cast<uint64_t>(static_cast<uint32_t>(doc + 1)) << 32) | __float_as_uint(s1);
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (SAMPLE) {
+    float* dst = reinterpret_cast<float*>(out) + static_cast<int64_t>(r) * out_stride +
+                 (static_cast<int64_t>(blockIdx.x) * 16 + 2 * w + h) * 2;
+    dst[0] = mx0;
+    dst[1] = mx1;
+  } else {
+    __syncthreads();
+    if (threadIdx.x < kF32Queries) cnt[static_cast<int64_t>(blockIdx.x) * kF32Queries + threadIdx.x] = lcnt[threadIdx.x];
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+bool mfma_f32_path_supported(int64_t n_rows, int dim, int n_queries, int n_candidates, int space) {
+  const int ch = dim / kF32ChunkCols;
+  return space == DEWI_SPACE_COSINE && n_queries >= kMfmaF32MinQueries && dim % kF32ChunkCols == 0 && ch >= 1 && ch <= 6 &&
+         ch != 5 && n_rows >= 64 * 1024 && n_candidates <= 256;
+}
+
+MfmaF32Layout plan_mfma_f32(int64_t n_rows, int dim, int n_queries, int n_candidates, int compute_units) {
+  MfmaF32Layout m{};
+  auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+  m.groups = (n_queries + kF32Queries - 1) / kF32Queries;
+  m.q_pad = m.groups * kF32Queries;
+  m.n_tiles = (n_rows + kF32TileRows - 1) / kF32TileRows;
+  // Sample every `stride`-th tile: expected survivors per query ~ stride * c; keep that near 4 K (the select kernel
+  // stages up to 8 K records in LDS) and the sample at no less than one tile per workgroup of the chip.
+  int64_t stride = 4096 / (n_candidates > 0 ? n_candidates : 1);
+  if (stride > 128) stride = 128;
+  if (stride < 8) stride = 8;
+  while (stride > 8 && (m.n_tiles + stride - 1) / stride < compute_units) stride /= 2;
+  m.tile_stride = stride;
+  m.n_sample_tiles = (m.n_tiles + stride - 1) / stride;
+  m.sample_blocks = m.n_sample_tiles < compute_units ? static_cast<int>(m.n_sample_tiles) : compute_units;
+  m.sample_stride = static_cast<int64_t>(m.sample_blocks) * 32;          // group maxima per query
+  m.n_blocks = m.n_tiles < compute_units ? static_cast<int>(m.n_tiles) : compute_units;
+  m.n_seg = m.n_blocks;
+  // expected survivors per query and segment: stride * c / n_blocks; 8x head-room, at least 16 records
+  int64_t cap = (8 * stride * n_candidates + m.n_seg - 1) / m.n_seg;
+  m.seg_cap = static_cast<int>(cap < 16 ? 16 : cap);
+  size_t off = 0;
+  m.qn_off = off;      off += up(static_cast<size_t>(m.q_pad) * dim * 4);
+  m.thr_off = off;     off += up(static_cast<size_t>(m.q_pad) * 4);
+  m.cnt_off = off;     off += up(static_cast<size_t>(m.groups) * m.n_seg * kF32Queries * 4);
+  m.dense_off = off;   off += up(static_cast<size_t>(kF32Queries) * m.sample_stride * 4);
+  m.cand_off = off;    off += up(static_cast<size_t>(m.groups) * m.n_seg * kF32Queries * m.seg_cap * 8);
+  m.total = off;
+  return m;
+}
+
+template <int CH>
+static hipError_t run_mfma_f32_dim(const MfmaF32Layout& m, const float* E, int64_t n_rows, int n_queries, int n_candidates,
+                                   char* ws, hipStream_t stream) {
+  constexpr int DIM = CH * kF32ChunkCols;
+  static PerDeviceOnce attr_once;   // one per CH instantiation
+  const hipError_t ea = attr_once.run([] {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan_f32<CH, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kF32LdsBytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan_f32<CH, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kF32LdsBytes);
+  });
+  if (ea != hipSuccess) return ea;
+  const float* qn = reinterpret_cast<const float*>(ws + m.qn_off);
+  float* thr = reinterpret_cast<float*>(ws + m.thr_off);
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(ws + m.cnt_off);
+  float* dense = reinterpret_cast<float*>(ws + m.dense_off);
+  uint64_t* cand = reinterpret_cast<uint64_t*>(ws + m.cand_off);
+  for (int g = 0; g < m.groups; ++g) {
+    const float* qg = qn + static_cast<int64_t>(g) * kF32Queries * DIM;
+    float* tg = thr + g * kF32Queries;
+    uint32_t* cg = cnt + static_cast<int64_t>(g) * m.n_seg * kF32Queries;
+    uint64_t* og = cand + static_cast<int64_t>(g) * m.n_seg * kF32Queries * m.seg_cap;
+    const int n_active = n_queries - g * kF32Queries < kF32Queries ? n_queries - g * kF32Queries : kF32Queries;
+    // 1. group maxima over the strided sample
+    hipLaunchKernelGGL((mfma_scan_f32<CH, true>), dim3(m.sample_blocks), dim3(kF32Threads), kF32LdsBytes, stream, E, n_rows, qg,
+                       m.n_sample_tiles, m.tile_stride, static_cast<const float*>(nullptr), reinterpret_cast<uint64_t*>(dense),
+                       m.sample_stride, static_cast<uint32_t*>(nullptr), n_active);
+    // 2. per-query threshold: the c-th largest group maximum (real queries only)
+    const hipError_t et = launch_sample_threshold(dense, m.sample_stride, m.sample_stride, n_candidates, tg, n_active, stream);
+    if (et != hipSuccess) return et;
+    // 3. the full pass with the filter (the kernel dewi_timing_read reports: algorithmic bytes = n_rows * dim * 4)
+    timing_begin(stream);
+    hipLaunchKernelGGL((mfma_scan_f32<CH, false>), dim3(m.n_blocks), dim3(kF32Threads), kF32LdsBytes, stream, E, n_rows, qg,
+                       m.n_tiles, static_cast<int64_t>(1), static_cast<const float*>(tg), og, static_cast<int64_t>(m.seg_cap), cg,
+                       n_active);
+    timing_end(stream);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_mfma_f32(const MfmaF32Layout& m, const float* d_E, int64_t n_rows, int dim, const float* d_Q, int n_queries,
+                           int n_candidates, int space, char* ws, hipStream_t stream) {
+  // normalised fp32 queries, zero rows behind the real ones (a padding query scores 0 everywhere; its threshold
+  // is forced to +inf in the kernel)
+  hipError_t e = launch_prepare_queries_padded(d_Q, reinterpret_cast<float*>(ws + m.qn_off), n_queries, m.q_pad, dim, space, stream);
+  if (e != hipSuccess) return e;
+  switch (dim / kF32ChunkCols) {
+    case 1: return run_mfma_f32_dim<1>(m, d_E, n_rows, n_queries, n_candidates, ws, stream);
+    case 2: return run_mfma_f32_dim<2>(m, d_E, n_rows, n_queries, n_candidates, ws, stream);
+    case 3: return run_mfma_f32_dim<3>(m, d_E, n_rows, n_queries, n_candidates, ws, stream);
+    case 4: return run_mfma_f32_dim<4>(m, d_E, n_rows, n_queries, n_candidates, ws, stream);
+    case 6: return run_mfma_f32_dim<6>(m, d_E, n_rows, n_queries, n_candidates, ws, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace dewi

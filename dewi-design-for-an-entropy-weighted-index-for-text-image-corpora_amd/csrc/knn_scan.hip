@@ -242,10 +242,14 @@ __global__ __launch_bounds__(kScanThreads) void scan_generic_f32(const float* __
 // Query preparation for the generic path: one wave per query, cosine -> q / ||q|| unless 0.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kWave) void prepare_queries_f32(const float* __restrict__ Q, float* __restrict__ Qn,
-                                                             int dim, int space, int to_bf16) {
+                                                             int dim, int space, int to_bf16, int n_real) {
   const int lane = lane_id();
   const float* q = Q + static_cast<int64_t>(blockIdx.x) * dim;
   float* o = Qn + static_cast<int64_t>(blockIdx.x) * dim;
+  if (static_cast<int>(blockIdx.x) >= n_real) {   // padding row of a 32-query block
+    for (int j = lane; j < dim; j += kWave) o[j] = 0.f;
+    return;
+  }
   float norm = 1.f;
   bool scale = false;
   if (space == DEWI_SPACE_COSINE) {
@@ -266,7 +270,13 @@ __global__ __launch_bounds__(kWave) void prepare_queries_f32(const float* __rest
 
 hipError_t launch_prepare_queries(const float* d_q, float* d_qn, int n_queries, int dim, int space, int to_bf16,
                                   hipStream_t stream) {
-  hipLaunchKernelGGL(prepare_queries_f32, dim3(n_queries), dim3(kWave), 0, stream, d_q, d_qn, dim, space, to_bf16);
+  hipLaunchKernelGGL(prepare_queries_f32, dim3(n_queries), dim3(kWave), 0, stream, d_q, d_qn, dim, space, to_bf16, n_queries);
+  return hipGetLastError();
+}
+
+hipError_t launch_prepare_queries_padded(const float* d_q, float* d_qn, int n_queries, int n_rows_out, int dim, int space,
+                                         hipStream_t stream) {
+  hipLaunchKernelGGL(prepare_queries_f32, dim3(n_rows_out), dim3(kWave), 0, stream, d_q, d_qn, dim, space, 0, n_queries);
   return hipGetLastError();
 }
 

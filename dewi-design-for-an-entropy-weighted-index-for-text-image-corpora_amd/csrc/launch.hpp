@@ -80,6 +80,9 @@ ScanPlan plan_scan(int64_t n_rows, int dim, int elem_bytes, int n_candidates, in
 // to_bf16: additionally round the normalised query to bf16 (stored as the fp32 value it represents).
 hipError_t launch_prepare_queries(const float* d_q, float* d_qn, int n_queries, int dim, int space, int to_bf16,
                                   hipStream_t stream);
+// The same (fp32, not rounded) into n_rows_out >= n_queries rows; rows behind the real queries are zero.
+hipError_t launch_prepare_queries_padded(const float* d_q, float* d_qn, int n_queries, int n_rows_out, int dim, int space,
+                                         hipStream_t stream);
 // One corpus pass for queries [q0, q0+nq): emits plan.keys_per_query keys per query into
 // d_keys + q * plan.keys_per_query.
 hipError_t launch_scan_f32(const ScanPlan& plan, const float* d_E, int64_t n_rows, int dim, const float* d_q_raw,
@@ -112,6 +115,31 @@ MfmaLayout plan_mfma(int64_t n_rows, int dim, int n_queries, int n_candidates, i
 hipError_t launch_mfma_bf16(const MfmaLayout& m, const uint16_t* d_E, int64_t n_rows, int dim, const float* d_Q,
                             int n_queries, int n_candidates, int space, char* ws, int compute_units,
                             hipStream_t stream);
+
+// ---- knn_mfma_f32.hip: batched (32 queries per corpus pass) fp32 path on the matrix cores
+constexpr int kMfmaF32MinQueries = 5;  // fp32 corpus: batches of at least this many queries take the matrix-core path
+                                       // (1 M x 768: 4 queries per pass 0.47 ms on the row-per-wave kernel, 8 queries 0.68 ms)
+struct MfmaF32Layout {
+  int groups;              // passes of up to 32 queries
+  int q_pad;               // groups * 32
+  int64_t n_tiles;         // 32-row tiles
+  int64_t tile_stride;     // the sample pass takes every tile_stride-th tile
+  int64_t n_sample_tiles;
+  int sample_blocks;       // workgroups of the sample pass
+  int64_t sample_stride;   // group maxima per query (sample_blocks * 32)
+  int n_blocks;            // workgroups of the filter pass = survivor segments per query
+  int n_seg;
+  int seg_cap;             // records per (workgroup, query) segment
+  size_t qn_off, thr_off, cnt_off, dense_off, cand_off, total;
+};
+bool mfma_f32_path_supported(int64_t n_rows, int dim, int n_queries, int n_candidates, int space);
+MfmaF32Layout plan_mfma_f32(int64_t n_rows, int dim, int n_queries, int n_candidates, int compute_units);
+hipError_t launch_mfma_f32(const MfmaF32Layout& m, const float* d_E, int64_t n_rows, int dim, const float* d_Q, int n_queries,
+                           int n_candidates, int space, char* ws, hipStream_t stream);
+
+// Per-query threshold = the n_candidates-th largest of each query's sample values (knn_mfma_bf16.hip).
+hipError_t launch_sample_threshold(const float* dense, int64_t n_sample, int64_t stride, int n_candidates, float* thr,
+                                   int n_queries, hipStream_t stream);
 
 // ---- select_rerank.hip --------------------------------------------------------------------
 struct RerankParams {

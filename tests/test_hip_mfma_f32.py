@@ -1,0 +1,102 @@
+"""GPU parity tests of the batched fp32 matrix-core path (csrc/knn_mfma_f32.hip) through the C ABI.
+
+The path is taken for >= 5 queries over an fp32 corpus of >= 64 K rows with dim % 256 == 0 (<= 1536),
+cosine space, at most 256 candidates.  v_mfma_f32_32x32x2_f32 multiplies exactly and accumulates in
+fp32, so the oracle comparison is the plain fp32 one (tests/parity.py: ids exactly wherever the f64
+decision gaps exceed 5e-7, scores to 1e-5).  ``search_device`` is called, so a refused query (-1) would
+be seen, not repaired.
+"""
+import numpy as np
+import pytest
+
+import dewi_oracle as orc
+from parity import check_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _corpus(n, dim, seed):
+    from dewi import _engine as eng
+    raw = orc.synth_corpus(n, dim, seed=seed)
+    cols = orc.synth_payload_columns(n, seed=seed)
+    c = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    return c, c.emb.cpu().numpy(), dewi32, ent32
+
+
+@pytest.mark.parametrize("dim,n,b,k", [(768, 70_001, 32, 10), (768, 66_000, 5, 10), (512, 80_000, 70, 10),
+                                       (256, 131_073, 33, 100), (1024, 65_536, 8, 10), (1536, 65_600, 17, 10),
+                                       (768, 300_000, 64, 128)])
+def test_mfma_f32_batched_vs_oracle(dim, n, b, k):
+    import torch
+    from dewi import _engine as eng
+    c, E, dewi32, ent32 = _corpus(n, dim, seed=dim + b)
+    Q = orc.synth_queries(b, dim, seed=b)
+    ids_d, sc_d = c.search_device(torch.from_numpy(Q).cuda(), k, 0.3, 0.1)
+    ids, sc = ids_d.cpu().numpy(), sc_d.cpu().numpy()
+    assert ids.min() >= 0 and not np.isnan(sc).any()             # no query was refused (nothing repaired here)
+    check_batch(E, Q, dewi32, ent32, k, 0.3, 0.1, "cosine", ids, sc, min_decisive_frac=0.8 if k <= 10 else 0.5,
+                exact_gaps=False)
+    # deterministic, and the same rows as the row-per-wave kernels (matrix-core path switched off): the two paths
+    # sum in different orders, so rare near-tie swaps only
+    ids2, sc2 = c.search_device(torch.from_numpy(Q).cuda(), k, 0.3, 0.1)
+    assert np.array_equal(ids2.cpu().numpy(), ids) and np.array_equal(sc2.cpu().numpy(), sc)
+    eng.tuning(0, 0, -1, 0)
+    try:
+        ids_s, sc_s = c.search(Q[:8], k, 0.3, 0.1)
+    finally:
+        eng.tuning(0, 0, -1, 1)
+    assert np.mean(ids_s == ids[:8]) > 0.98
+    assert np.allclose(np.sort(sc_s, axis=1), np.sort(sc[:8], axis=1), rtol=0, atol=2e-6)
+
+
+def test_mfma_f32_a_batch_of_four_stays_on_the_scan_kernels_and_agrees():
+    """Batches of 2-4 queries keep the row-per-wave kernels (one pass for four queries is as fast); the answers of
+    the two paths for the same queries must be interchangeable."""
+    import torch
+    c, E, dewi32, ent32 = _corpus(70_000, 768, seed=11)
+    Q = orc.synth_queries(12, 768, seed=12)
+    ids12, sc12 = c.search(Q, 10, 0.3, 0.0)                       # matrix-core path
+    ids4 = np.concatenate([c.search(Q[i:i + 4], 10, 0.3, 0.0)[0] for i in (0, 4, 8)])
+    assert np.mean(ids4 == ids12) > 0.98
+    check_batch(E, Q, dewi32, ent32, 10, 0.3, 0.0, "cosine", ids12, sc12, exact_gaps=False)
+
+
+def test_mfma_f32_overflow_falls_back_to_exact_path():
+    """40 000 exact duplicates of a query's best document overflow that query's survivor segments; the marker
+    (-1) makes the blocking search re-run it on the exact kernels."""
+    from dewi import _engine as eng
+    import torch
+    n, dim, k = 100_000, 256, 10
+    raw = orc.synth_corpus(n, dim, seed=3)
+    raw[50_000:90_000] = raw[7]
+    cols = orc.synth_payload_columns(n, seed=3)
+    c = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    Q = orc.synth_queries(16, dim, seed=4)
+    Q[5] = raw[7]
+    ids_raw, _ = c.search_device(torch.from_numpy(Q).cuda(), k, 0.0, 0.0)
+    ids_raw = ids_raw.cpu().numpy()
+    assert (ids_raw[5] == -1).all() and (np.delete(ids_raw, 5, axis=0) >= 0).all()
+    ids, sc = c.search(Q, k, 0.0, 0.0)
+    assert ids[5].tolist() == [7] + list(range(50_000, 50_009))
+    assert np.allclose(sc[5], 1.0, atol=1e-5)
+
+
+def test_mfma_f32_shard_candidates_and_merge_equal_whole():
+    """Two fp32 shards answered by the matrix-core path (dewi_knn_candidates) + merge == the whole corpus."""
+    import torch
+    from dewi import _engine as eng
+    n, d, k = 140_000, 256, 10
+    raw = orc.synth_corpus(n, d, seed=21)
+    cols = orc.synth_payload_columns(n, seed=21)
+    Q = torch.from_numpy(orc.synth_queries(20, d, seed=22)).cuda()
+    whole = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    ids_w, sc_w = whole.search_device(Q, k, 0.3, 0.2)
+    lists = []
+    for lo, hi in ((0, 70_000), (70_000, n)):
+        sub = {key: v[lo:hi] for key, v in cols.items()}
+        sh = eng.DeviceCorpus.from_host(raw[lo:hi], sub["dewi"], sub["ht_mean"], sub["hi_mean"], id_offset=lo)
+        lists.append(sh.candidates_device(Q, 2 * k))
+    ids, sc = eng.merge_rerank_device(torch.stack(lists), 2 * k, k, 0.3, 0.2)
+    # per-row sums are the same whichever shard a row is in (same kernel, same depth split), so bit-equal
+    assert torch.equal(ids, ids_w) and torch.equal(sc, sc_w)
