@@ -51,8 +51,8 @@ constexpr int kF32ChunkCols = 256;
 constexpr int kF32ChunkBytes = kF32TileRows * kF32ChunkCols * 4;   // 32 KiB
 constexpr int kF32Ring = 4;
 [[maybe_unused]] constexpr int kF32PiecesPerWave = kF32TileRows / kF32Waves;        // 4 rows (= 1 KiB pieces) per wave and chunk
-constexpr int kF32RedRegs = 14;                                     // partial registers a wave hands over (all but its own two)
-constexpr int kF32RedBytes = kF32Waves * kF32RedRegs * kWave * 4;   // 28 KiB
+constexpr int kF32RedRegs = 15;                                     // LDS slots per wave: the 14 registers it hands over + a spare
+constexpr int kF32RedBytes = kF32Waves * kF32RedRegs * kWave * 4;   // 30 KiB
 constexpr int kF32LdsBytes = kF32Ring * kF32ChunkBytes + kF32RedBytes + kF32Queries * 4;
 #ifndef DEWI_F32MFMA_DMA_AUX
 #define DEWI_F32MFMA_DMA_AUX 2   // non-temporal tile DMA: the corpus is read once
@@ -120,13 +120,6 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const float* __r
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Eb + row0 * row_bytes), 0, valid * static_cast<int>(row_bytes),
                                              0x00020000);
   };
-  auto issue_chunk = [&](__amdgpu_buffer_rsrc_t rsrc, int ch, int slot) {
-    char* base = lds + slot * kF32ChunkBytes + w * 1024;
-#pragma unroll
-    for (int p = 0; p < kF32PiecesPerWave; ++p)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtrF)(base + p * 8 * 1024), 16, (p & 1) ? voff_odd : voff_even,
-                                               p * 8 * static_cast<int>(row_bytes) + ch * 1024, 0, DEWI_F32MFMA_DMA_AUX);
-  };
   // ---- A-fragment read addresses inside ring slot 0: row r, unit (8 w + 2 m + h) ^ (r & 15)
   uint32_t a_addr[4];
 #pragma unroll
@@ -134,71 +127,48 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const float* __r
     a_addr[m] = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((LdsPtrF)(lds))) +
                 static_cast<uint32_t>(r * 1024 + 16 * ((8 * w + 2 * m + h) ^ (r & 15)));
 
-  // chunk sequence of this workgroup: g = it * CH + ch -> ring slot g & 3.  Chunks g+1 .. g+3 are in flight while
-  // chunk g is multiplied; chunks past the last tile are fetched through an empty descriptor (zeros, no memory
-  // traffic) so that the count of outstanding pieces — and with it every vmcnt below — is the same on every
-  // iteration.
-  auto issue_g = [&](int64_t g) {
+  // ---- Software pipeline.  Chunk sequence of this workgroup: g = it * CH + ch -> ring slot g & 3.  Iteration g
+  //   waits for chunk g+1 (own pieces: vmcnt, everybody's: barrier), starts the LDS reads of chunk g+1, and
+  //   MULTIPLIES CHUNK g FROM REGISTERS (read during iteration g-1), so the matrix pipe starts right behind the
+  //   barrier; the four DMA pieces of chunk g+4 go out BETWEEN the MFMAs — an fp32 MFMA occupies the pipe for 64
+  //   cycles (128 with the partner wave's in between), which covers a piece's issue — instead of in front of them,
+  //   where both waves of a SIMD left the pipe idle together (first version of this kernel: matrix pipe busy 60 %).
+  //   Chunk g+4 refills the slot of chunk g, which every wave has finished reading before the barrier of
+  //   iteration g.  Chunks past the last tile are fetched through an empty descriptor (zeros, no memory traffic)
+  //   so that every iteration has the same 12 pieces outstanding at its vmcnt(8).
+  auto issue_piece = [&](__amdgpu_buffer_rsrc_t rsrc, int ch, int slot, int p) {
+    char* base = lds + slot * kF32ChunkBytes + w * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtrF)(base + p * 8 * 1024), 16, (p & 1) ? voff_odd : voff_even,
+                                             p * 8 * static_cast<int>(row_bytes) + ch * 1024, 0, DEWI_F32MFMA_DMA_AUX);
+  };
+  auto issue_g = [&](int64_t g) {   // run-time chunk index (prologue only)
     const int64_t it = g / CH;
     const int ch = static_cast<int>(g - it * CH);
     const __amdgpu_buffer_rsrc_t rs = tile_rsrc(it);
     const int slot = static_cast<int>(g & 3);
-    // ch is a run-time value here (prologue); the loop below calls issue_chunk with compile-time ch
-    switch (ch) {
-      case 0: issue_chunk(rs, 0, slot); break;
-      case 1: if constexpr (CH > 1) issue_chunk(rs, 1, slot); break;
-      case 2: if constexpr (CH > 2) issue_chunk(rs, 2, slot); break;
-      case 3: if constexpr (CH > 3) issue_chunk(rs, 3, slot); break;
-      case 4: if constexpr (CH > 4) issue_chunk(rs, 4, slot); break;
-      default: if constexpr (CH > 5) issue_chunk(rs, 5, slot); break;
-    }
-  };
-  if (n_my > 0) {
-    issue_g(0);
-    issue_g(1);
-    issue_g(2);
-  }
-
-  float mx0 = -__builtin_inff(), mx1 = -__builtin_inff();
-  f32x16f acc;
-  for (int64_t it = 0; it < n_my; ++it) {
 #pragma unroll
-    for (int ch = 0; ch < CH; ++ch) {
-      const int64_t g = it * CH + ch;
-      const int slot = static_cast<int>(g & 3);
-      // own pieces of chunk g have landed: of the 12 pieces this wave has outstanding (chunks g, g+1, g+2) all
-      // but the 8 youngest are done (vector-memory operations retire in issue order; a survivor store in between
-      // only makes the wait stricter)
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      // one barrier per chunk: every wave's pieces of chunk g are in LDS, and every wave has finished reading the
-      // slot of chunk g-1, which chunk g+3 now refills
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      issue_chunk(tile_rsrc(it + (ch + 3) / CH), (ch + 3) % CH, static_cast<int>((g + 3) & 3));
-      const uint32_t slot_off = static_cast<uint32_t>(slot) * kF32ChunkBytes;
-      f32x4f a[4];
+    for (int c = 0; c < CH; ++c) {
+      if (ch == c) {
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
-        asm volatile("ds_read_b128 %0, %1" : "=v"(a[m]) : "v"(a_addr[m] + slot_off));
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        // LDS returns data in order: before fragment m is used at most the 3 - m younger reads may be pending
-        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a[m]) : "n"(3 - m));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const f32x16f zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][i], qf[ch][m][i], (ch == 0 && m == 0 && i == 0) ? zero : acc, 0, 0, 0);
-        }
+        for (int p = 0; p < kF32PiecesPerWave; ++p) issue_piece(rs, c, slot, p);
       }
     }
-    // ---- tile epilogue: sum the eight depth partials; wave w ends up with registers 2w and 2w+1 of the block
-    // D[doc = (j & 3) + 8 (j >> 2) + 4 h][query = r].  Partials of register j from wave v sit at
-    // red[(v * 14 + (j < 2v ? j : j - 2)) * 64 + lane] (a wave does not store the two registers it keeps).
+  };
+  auto read_chunk = [&](f32x4f (&dst)[4], int slot) {
+    const uint32_t slot_off = static_cast<uint32_t>(slot) * kF32ChunkBytes;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) asm volatile("ds_read_b128 %0, %1" : "=v"(dst[m]) : "v"(a_addr[m] + slot_off));
+  };
+  // partial sums: wave v keeps register j at red[(v * 15 + slot_of(j, v)) * 64 + lane]; its own two registers go
+  // to the spare slot 14 (never read), which keeps the stores free of branches
+  const uint32_t red_addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((LdsPtrF)(red))) + 4u * static_cast<uint32_t>(lane);
+  float own0 = 0.f, own1 = 0.f;
+  auto stage1_store = [&](const f32x16f& acc) {     // hand the other waves their registers of this wave's partial block
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      if (j != 2 * w && j != 2 * w + 1) red[(w * kF32RedRegs + (j < 2 * w ? j : j - 2)) * kWave + lane] = acc[j];
+      const int sl = j < 2 * w ? j : (j > 2 * w + 1 ? j - 2 : 14);
+      asm volatile("ds_write_b32 %0, %1" ::"v"(red_addr + static_cast<uint32_t>((w * kF32RedRegs + sl) * kWave * 4)), "v"(acc[j]) : "memory");
     }
-    float own0 = 0.f, own1 = 0.f;
 #pragma unroll
     for (int ww = 0; ww < kF32Waves; ++ww) {
       if (w == ww) {
@@ -206,27 +176,28 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const float* __r
         own1 = acc[2 * ww + 1];
       }
     }
-    // LDS stores are complete when lgkmcnt reaches 0 (not __syncthreads(): its release fence would also wait
-    // for vmcnt(0) and drain the DMA ring at every tile end)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+  };
+  float part[kF32Waves][2];
+  auto stage2_load = [&]() {                         // registers 2w, 2w+1 of every wave's partial block (own: spare slot)
+#pragma unroll
+    for (int v = 0; v < kF32Waves; ++v) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int j = 2 * w + e;
+        const int sl = v == w ? 14 : (w < v ? j : j - 2);
+        asm volatile("ds_read_b32 %0, %1" : "=v"(part[v][e]) : "v"(red_addr + static_cast<uint32_t>((v * kF32RedRegs + sl) * kWave * 4)));
+      }
+    }
+  };
+  float mx0 = -__builtin_inff(), mx1 = -__builtin_inff();
+  auto stage2_finish = [&](int64_t it) {             // fixed summation order 0..7 whichever wave sums; then the filter
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-    for (int v = 0; v < kF32Waves; ++v) {     // fixed order 0..7 whichever wave does the sum
-      float p0, p1;
-      if (v == w) {
-        p0 = own0;
-        p1 = own1;
-      } else {
-        const int j0 = 2 * w, j1 = 2 * w + 1;
-        p0 = red[(v * kF32RedRegs + (j0 < 2 * v ? j0 : j0 - 2)) * kWave + lane];
-        p1 = red[(v * kF32RedRegs + (j1 < 2 * v ? j1 : j1 - 2)) * kWave + lane];
-      }
+    for (int v = 0; v < kF32Waves; ++v) {
+      const float p0 = v == w ? own0 : part[v][0], p1 = v == w ? own1 : part[v][1];
       s0 = v == 0 ? p0 : s0 + p0;
       s1 = v == 0 ? p1 : s1 + p1;
     }
-    // (the next write to `red` is a whole tile — CH chunk barriers — away: no barrier needed behind these reads)
     const int64_t row0 = (first + it * step) * tile_stride * kF32TileRows;
     const int64_t doc = row0 + 2 * (w & 1) + 8 * (w >> 1) + 4 * h;     // register 2w; register 2w+1 is the next row
     if (doc >= n_rows) s0 = -__builtin_inff();                         // padding rows of the last tile never pass
@@ -258,6 +229,78 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const float* __r
         }
       }
     }
+  };
+
+  f32x4f cur[4], nxt[4];
+  f32x16f acc;
+  if (n_my > 0) {
+    issue_g(0);
+    issue_g(1);
+    issue_g(2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // own pieces of chunk 0
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue_g(3);
+    read_chunk(cur, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
+  }
+  for (int64_t it = 0; it < n_my; ++it) {
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+      const int64_t g = it * CH + ch;
+      // own pieces of chunk g+1 have landed: of the 12 pieces outstanding (chunks g+1, g+2, g+3) all but the 8
+      // youngest are done (vector-memory operations retire in issue order; a survivor store in between only makes
+      // the wait stricter)
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      // one barrier per chunk: every wave's pieces of chunk g+1 are in LDS, every wave has finished reading chunk g
+      // (its slot is refilled below), and — first chunk of a tile — the partial sums of the previous tile are in LDS
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      read_chunk(nxt, static_cast<int>((g + 1) & 3));
+      const bool finish_prev = ch == 0 && it > 0;      // the previous tile's partials were stored before this barrier
+      if (finish_prev) stage2_load();
+      const __amdgpu_buffer_rsrc_t rs4 = tile_rsrc(it + (ch + 4) / CH);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f32x16f zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[m][i], qf[ch][m][i], (ch == 0 && m == 0 && i == 0) ? zero : acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        issue_piece(rs4, (ch + 4) % CH, static_cast<int>((g + 4) & 3), m);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // chunk g+1's fragments (and the previous tile's partials) are in registers
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]));
+      if (finish_prev) {
+#pragma unroll
+        for (int v = 0; v < kF32Waves; ++v) asm volatile("" : "+v"(part[v][0]), "+v"(part[v][1]));
+        stage2_finish(it - 1);
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) cur[m] = nxt[m];
+      if (ch == CH - 1) {
+        // the tile's block is complete in this wave's depth slice: hand the partials over.  With one chunk per tile
+        // the other waves may still be reading the previous tile's partials (no barrier since): wait for them.
+        if constexpr (CH == 1) {
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+        }
+        stage1_store(acc);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // stores complete before the next barrier publishes them
+      }
+    }
+  }
+  if (n_my > 0) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    stage2_load();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int v = 0; v < kF32Waves; ++v) asm volatile("" : "+v"(part[v][0]), "+v"(part[v][1]));
+    stage2_finish(n_my - 1);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (SAMPLE) {
