@@ -72,6 +72,18 @@ __device__ __forceinline__ float wave_query_norm(double ss) {
 }
 __device__ __forceinline__ double square_f64(float v) { return static_cast<double>(v) * static_cast<double>(v); }
 
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#define DEWI_STEP(CTRL, MASK) v = v + static_cast<uint32_t>(dpp_i32<CTRL, MASK>(0, static_cast<int>(v)));
+  DEWI_STEP(0xB1, 0xF)
+  DEWI_STEP(0x4E, 0xF)
+  DEWI_STEP(0x124, 0xF)
+  DEWI_STEP(0x128, 0xF)
+  DEWI_STEP(0x142, 0xA)
+  DEWI_STEP(0x143, 0xC)
+#undef DEWI_STEP
+  return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
+}
+
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 #define DEWI_STEP(CTRL, MASK)                                                        \
   {                                                                                  \

@@ -188,6 +188,13 @@ hipError_t launch_payload_soa(const double* dewi, const double* ht, const double
 
 // ---- robust_stats.hip ---------------------------------------------------------------------
 size_t robust_fit_workspace_bytes(int n_signals);
+// robust_fit_fast.hip: the two-launch fit of one device's columns (bracket from a sample, one pass, exact select
+// among the collected keys).  Its workspace region follows the histogram path's inside the caller's workspace.
+constexpr int64_t kFitFastCap = 1024 * 1024;   // keys the compact buffer of a column holds (4 MiB)
+size_t robust_fit_fast_bytes(int n_signals);
+bool robust_fit_fast_supported(int64_t n, int n_signals);
+hipError_t launch_robust_fit_fast(const float* d_S, int64_t n, int64_t ld, int n_signals, float* d_med, float* d_mad,
+                                  void* d_fast_ws, hipStream_t stream);
 void robust_fit_region(int n_signals, int phase, int pass, int which, size_t* offset_bytes, size_t* count_u32);
 hipError_t launch_fit_begin(void* d_ws, int n_signals, hipStream_t stream);
 hipError_t launch_fit_hist(const float* S, int64_t n, int64_t ld, int n_signals, int phase, int pass, const float* med,

@@ -48,9 +48,15 @@ static FitWorkspace carve(void* ws, int n_signals) {
   return w;
 }
 
-size_t robust_fit_workspace_bytes(int n_signals) {
+static size_t hist_path_bytes(int n_signals) {
   const size_t P = 2 * static_cast<size_t>(n_signals);
-  return sizeof(uint32_t) * 2 * 3 * P * kBins + sizeof(FitState) * 2 * P + sizeof(uint32_t) * 2 * n_signals + 256;
+  const size_t b = sizeof(uint32_t) * 2 * 3 * P * kBins + sizeof(FitState) * 2 * P + sizeof(uint32_t) * 2 * n_signals + 256;
+  return (b + 255) / 256 * 256;
+}
+
+size_t robust_fit_workspace_bytes(int n_signals) {
+  // [histogram path (also the sharded fit's pieces) | two-launch path of robust_fit_fast.hip]
+  return hist_path_bytes(n_signals) + robust_fit_fast_bytes(n_signals);
 }
 
 template <int PASS>
@@ -235,7 +241,7 @@ void robust_fit_region(int n_signals, int phase, int pass, int which, size_t* of
 }
 
 hipError_t launch_fit_begin(void* d_ws, int n_signals, hipStream_t stream) {
-  return hipMemsetAsync(d_ws, 0, robust_fit_workspace_bytes(n_signals), stream);
+  return hipMemsetAsync(d_ws, 0, hist_path_bytes(n_signals), stream);
 }
 
 hipError_t launch_fit_hist(const float* S, int64_t n, int64_t ld, int n_signals, int phase, int pass, const float* med,
@@ -284,6 +290,9 @@ hipError_t launch_fit_finish(int64_t n_total, int n_signals, int phase, void* d_
 
 hipError_t launch_robust_fit(const float* d_S, int64_t n, int64_t ld, int n_signals, float* d_med, float* d_mad,
                              void* d_ws, hipStream_t stream) {
+  if (robust_fit_fast_supported(n, n_signals))   // one device, columns the compact buffers hold: two launches
+    return launch_robust_fit_fast(d_S, n, ld, n_signals, d_med, d_mad, static_cast<char*>(d_ws) + hist_path_bytes(n_signals),
+                                  stream);
   hipError_t e = launch_fit_begin(d_ws, n_signals, stream);
   if (e != hipSuccess) return e;
   for (int phase = 0; phase < 2; ++phase) {

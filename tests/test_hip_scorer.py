@@ -121,3 +121,59 @@ def test_score_1m_rows_matches_oracle():
         got = s.score_batch(cols, mode)
         ref = orc.score({k: v.astype(np.float64) for k, v in cols.items()}, med, mad, None, 3.0, mode)
         assert np.max(np.abs(got - ref) / ref) <= 4e-16
+
+
+@pytest.mark.parametrize("n", [65_537, 100_003, 400_000, 1_000_000])
+def test_fast_fit_adversarial_columns_stay_exact(n):
+    """The two-launch fit (csrc/robust_fit_fast.hip) guesses a bracket from a strided sample and VERIFIES it; when
+    the guess is wrong — data arranged against the sample — or a buffer overflows, the last workgroup selects over
+    the whole column instead.  Either way the order statistics must be NumPy's, bit for bit."""
+    from dewi.scorer import RobustStats
+    rs = np.random.RandomState(n)
+    stride = n // 8192
+    periodic = rs.randn(n).astype(np.float32)
+    periodic[(np.arange(8192) * 2 + 1) * n // (2 * 8192)] = 1e6           # every SAMPLED position holds an outlier
+    heavy_zero = np.where(rs.rand(n) < 0.7, 0.0, rs.gamma(2, 0.5, n)).astype(np.float32)   # 70 % ties at the median
+    few_values = rs.choice(np.array([0.25, 0.5, 0.75], np.float32), n)     # three distinct values: lo == hi likely
+    bimodal = np.where(np.arange(n) % 2 == 0, rs.randn(n) - 50, rs.randn(n) + 50).astype(np.float32)   # empty middle
+    cols = {
+        "sorted_up": np.sort(rs.randn(n).astype(np.float32)),
+        "sorted_down": np.sort(rs.randn(n).astype(np.float32))[::-1].copy(),
+        "periodic_outliers": periodic,
+        "heavy_zero": heavy_zero,
+        "few_values": few_values,
+        "constant": np.full(n, 3.25, np.float32),
+        "bimodal": bimodal,
+        "blocks": np.repeat(rs.randn(n // stride + 1).astype(np.float32), stride)[:n].copy(),   # runs of equal values
+        "negatives": (-rs.gamma(2, 0.5, n)).astype(np.float32),
+        "mixed_nan": np.where(np.arange(n) == n // 3, np.nan, rs.randn(n)).astype(np.float32),
+    }
+    st = RobustStats.fit_columns(cols)
+    med, mad = orc.robust_fit(cols)
+    for k in cols:
+        same_med = st.medians[k] == med[k] or (np.isnan(st.medians[k]) and np.isnan(med[k]))
+        same_mad = st.mads[k] == mad[k] or (np.isnan(st.mads[k]) and np.isnan(mad[k]))
+        assert same_med and same_mad, (k, st.medians[k], med[k], st.mads[k], mad[k])
+
+
+def test_fast_fit_through_the_c_abi_with_a_leading_dimension():
+    """dewi_robust_fit_f32 with ld > n (columns not 16-byte aligned): head / body / tail of every slice exactly once."""
+    import torch
+    from dewi import _native as nat
+    lib = nat.load_library()
+    n, ld, ns = 300_001, 300_007, 3
+    rs = np.random.RandomState(1)
+    host = np.zeros((ns, ld), np.float32)
+    host[:, :n] = rs.gamma(2, 0.5, (ns, n)).astype(np.float32)
+    host[:, n:] = 1e9                                   # padding behind the columns must not be read
+    dev = torch.from_numpy(host).cuda()
+    med = torch.empty(ns, dtype=torch.float32, device="cuda")
+    mad = torch.empty(ns, dtype=torch.float32, device="cuda")
+    wsb = int(lib.dewi_robust_fit_workspace_bytes(ns))
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    for _ in range(3):                                  # repeated calls reuse the workspace (counters are re-zeroed)
+        nat.check(lib.dewi_robust_fit_f32(nat.ptr(dev), n, ld, ns, nat.ptr(med), nat.ptr(mad), nat.ptr(ws), wsb, nat.stream_ptr()))
+    m, d = med.cpu().numpy(), mad.cpu().numpy()
+    for s in range(ns):
+        want = np.median(host[s, :n])
+        assert m[s] == want and d[s] == np.median(np.abs(host[s, :n] - want))
