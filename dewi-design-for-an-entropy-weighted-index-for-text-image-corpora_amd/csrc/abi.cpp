@@ -220,7 +220,13 @@ int knn_rerank_impl(const void* d_E, int elem_type, int64_t n_rows, int dim, con
   rc = ensure_device(dev);
   if (rc) return rc;
   char* ws = static_cast<char*>(d_ws);
-  if (elem_type == 1 && g_tuning.mfma != 0 && dewi::mfma_path_supported(n_rows, dim, n_queries, c, space)) {
+  // Which batched path?  fp32 corpus: the depth-split matrix-core pass (32 queries per pass).  bf16 corpus: up to 32
+  // queries -> the depth-split pass (tile-delivery rate); more -> the 256-query kernel where it holds the dimension
+  // in registers (dim <= 768), else depth-split passes of 32.
+  const bool depth_ok = g_tuning.mfma != 0 && dewi::mfma_f32_path_supported(elem_type, n_rows, dim, n_queries, c, space);
+  const bool big_ok = elem_type == 1 && g_tuning.mfma != 0 && dewi::mfma_path_supported(n_rows, dim, n_queries, c, space);
+  const bool use_depth = depth_ok && (elem_type == 0 || n_queries <= 32 || !big_ok);
+  if (big_ok && !use_depth) {
     // many queries over a bf16 corpus: matrix-core path, one corpus pass per 256 queries
     const dewi::MfmaLayout M = dewi::plan_mfma(n_rows, dim, n_queries, c, dev.cus);
     if (!d_ws || ws_bytes < M.total) return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, M.total);
@@ -244,11 +250,11 @@ int knn_rerank_impl(const void* d_E, int elem_type, int64_t n_rows, int dim, con
     if (e != hipSuccess) return hip_fail(e, "select_rerank launch");
     return DEWI_OK;
   }
-  if (elem_type == 0 && g_tuning.mfma != 0 && dewi::mfma_f32_path_supported(n_rows, dim, n_queries, c, space)) {
-    // 5+ queries over an fp32 corpus: matrix-core path, one corpus pass per 32 queries
-    const dewi::MfmaF32Layout M = dewi::plan_mfma_f32(n_rows, dim, n_queries, c, dev.cus);
+  if (use_depth) {
+    // depth-split matrix-core path, one corpus pass per 32 queries
+    const dewi::MfmaF32Layout M = dewi::plan_mfma_f32(elem_type, n_rows, dim, n_queries, c, dev.cus);
     if (!d_ws || ws_bytes < M.total) return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, M.total);
-    hipError_t e = dewi::launch_mfma_f32(M, static_cast<const float*>(d_E), n_rows, dim, d_Q, n_queries, c, space, ws, stream);
+    hipError_t e = dewi::launch_mfma_f32(M, elem_type, d_E, n_rows, dim, d_Q, n_queries, c, space, ws, stream);
     if (e != hipSuccess) return hip_fail(e, "fp32 mfma scan launch");
     const dewi::RerankParams rp = make_rerank(eta, pref, transform, space);
     for (int g = 0; g < M.groups; ++g) {
@@ -347,9 +353,11 @@ size_t dewi_knn_workspace_bytes(int64_t n_rows, int dim, int n_queries, int n_ca
     const size_t m = dewi::plan_mfma(n_rows, dim, n_queries, n_candidates, dev.cus).total;
     if (m > a) a = m;
   }
-  if (dewi::mfma_f32_path_supported(n_rows, dim, n_queries, n_candidates, DEWI_SPACE_COSINE)) {
-    const size_t m = dewi::plan_mfma_f32(n_rows, dim, n_queries, n_candidates, dev.cus).total;
-    if (m > a) a = m;
+  for (int et = 0; et < 2; ++et) {
+    if (dewi::mfma_f32_path_supported(et, n_rows, dim, n_queries, n_candidates, DEWI_SPACE_COSINE)) {
+      const size_t m = dewi::plan_mfma_f32(et, n_rows, dim, n_queries, n_candidates, dev.cus).total;
+      if (m > a) a = m;
+    }
   }
   return a;  // valid for either element type and every path (small-batch scans, bf16 / fp32 matrix-core)
 }
@@ -459,8 +467,12 @@ int dewi_knn_candidates(const void* d_E, int elem_type, int64_t n_rows, int dim,
   if (rc) return rc;
   // a shard can contribute at most n_rows candidates; the rest of each list is padding
   const int c_local = n_candidates < n_rows ? n_candidates : static_cast<int>(n_rows);
-  if (elem_type == 1 && g_tuning.mfma != 0 && c_local == n_candidates &&
-      dewi::mfma_path_supported(n_rows, dim, n_queries, n_candidates, space)) {
+  const bool depth_ok = g_tuning.mfma != 0 && c_local == n_candidates &&
+                        dewi::mfma_f32_path_supported(elem_type, n_rows, dim, n_queries, n_candidates, space);
+  const bool big_ok = elem_type == 1 && g_tuning.mfma != 0 && c_local == n_candidates &&
+                      dewi::mfma_path_supported(n_rows, dim, n_queries, n_candidates, space);
+  const bool use_depth = depth_ok && (elem_type == 0 || n_queries <= 32 || !big_ok);
+  if (big_ok && !use_depth) {
     // many queries over a bf16 shard: matrix-core path; an overflowed query's records carry id -2
     const dewi::MfmaLayout M = dewi::plan_mfma(n_rows, dim, n_queries, n_candidates, dev.cus);
     if (!d_workspace || workspace_bytes < M.total)
@@ -484,15 +496,13 @@ int dewi_knn_candidates(const void* d_E, int elem_type, int64_t n_rows, int dim,
     if (e != hipSuccess) return hip_fail(e, "select (candidates) launch");
     return DEWI_OK;
   }
-  if (elem_type == 0 && g_tuning.mfma != 0 && c_local == n_candidates &&
-      dewi::mfma_f32_path_supported(n_rows, dim, n_queries, n_candidates, space)) {
-    // 5+ queries over an fp32 shard: matrix-core path; an overflowed query's records carry id -2
-    const dewi::MfmaF32Layout M = dewi::plan_mfma_f32(n_rows, dim, n_queries, n_candidates, dev.cus);
+  if (use_depth) {
+    // depth-split matrix-core path over a shard; an overflowed query's records carry id -2
+    const dewi::MfmaF32Layout M = dewi::plan_mfma_f32(elem_type, n_rows, dim, n_queries, n_candidates, dev.cus);
     if (!d_workspace || workspace_bytes < M.total)
       return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, M.total);
     char* wsm = static_cast<char*>(d_workspace);
-    hipError_t e = dewi::launch_mfma_f32(M, static_cast<const float*>(d_E), n_rows, dim, d_Q, n_queries, n_candidates, space,
-                                         wsm, stream);
+    hipError_t e = dewi::launch_mfma_f32(M, elem_type, d_E, n_rows, dim, d_Q, n_queries, n_candidates, space, wsm, stream);
     if (e != hipSuccess) return hip_fail(e, "fp32 mfma scan launch");
     const dewi::RerankParams rp0 = make_rerank(0.0, 0.0);
     for (int g = 0; g < M.groups; ++g) {

@@ -42,18 +42,33 @@ namespace dewi {
 
 typedef float f32x16f __attribute__((ext_vector_type(16)));
 typedef float f32x4f __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4f __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8f __attribute__((ext_vector_type(8)));
 
 constexpr int kF32Threads = 512;
 constexpr int kF32Waves = kF32Threads / kWave;       // 8: the depth split
 constexpr int kF32TileRows = 32;
 constexpr int kF32Queries = 32;                      // queries per pass (one MFMA column block)
 constexpr int kF32ChunkCols = 256;
-constexpr int kF32ChunkBytes = kF32TileRows * kF32ChunkCols * 4;   // 32 KiB
-constexpr int kF32Ring = 4;
-[[maybe_unused]] constexpr int kF32PiecesPerWave = kF32TileRows / kF32Waves;        // 4 rows (= 1 KiB pieces) per wave and chunk
+// Geometry of the two element types this kernel is built for.  fp32: a chunk row is 1 KiB = one DMA piece, chunk
+// 32 KiB, ring of 4 (3 chunks = 96 KiB in flight), per wave and chunk 4 pieces, 4 ds_read_b128 and 16 MFMAs
+// (32x32x2 f32).  bf16 (small query batches over a bf16 corpus; also dim 1024 / 1536): a chunk row is 512 B, a DMA
+// piece two rows, chunk 16 KiB, ring of 8 (7 chunks = 112 KiB in flight), per wave and chunk 2 pieces, 2
+// ds_read_b128 and 2 MFMAs (32x32x16 bf16) — a pure tile-delivery kernel: 49 GFLOP of bf16 are 20 us of matrix pipe.
+template <bool BF16>
+struct DepthGeo {
+  static constexpr int kElem = BF16 ? 2 : 4;
+  static constexpr int kRowChunk = kF32ChunkCols * kElem;             // bytes of a row inside a chunk: 1024 / 512
+  static constexpr int kChunk = kF32TileRows * kRowChunk;             // 32 KiB / 16 KiB
+  static constexpr int kRing = BF16 ? 8 : 4;
+  static constexpr int kPieces = kChunk / 1024 / kF32Waves;           // 1 KiB DMA pieces per wave and chunk: 4 / 2
+  static constexpr int kReads = BF16 ? 2 : 4;                         // ds_read_b128 per wave and chunk (== kPieces)
+  static constexpr int kWaitPieces = (kRing - 2) * kPieces;           // vmcnt that leaves chunk g+1 landed: 8 / 12
+};
 constexpr int kF32RedRegs = 15;                                     // LDS slots per wave: the 14 registers it hands over + a spare
 constexpr int kF32RedBytes = kF32Waves * kF32RedRegs * kWave * 4;   // 30 KiB
-constexpr int kF32LdsBytes = kF32Ring * kF32ChunkBytes + kF32RedBytes + kF32Queries * 4;
+template <bool BF16>
+constexpr int depth_lds_bytes() { return DepthGeo<BF16>::kRing * DepthGeo<BF16>::kChunk + kF32RedBytes + kF32Queries * 4; }
 #ifndef DEWI_F32MFMA_DMA_AUX
 #define DEWI_F32MFMA_DMA_AUX 2   // non-temporal tile DMA: the corpus is read once
 #endif
@@ -64,29 +79,35 @@ using LdsPtrF = void __attribute__((address_space(3)))*;
 // SAMPLE: out is a float array [32][out_stride]: out[q * out_stride + (16 * blockIdx.x + 2 * wave + h) * 2 + e] =
 //         the best score this lane's register e saw over the workgroup's tiles (32 group maxima per workgroup).
 // filter: raw records out[(blockIdx.x * 32 + q) * out_stride + slot], cnt[blockIdx.x * 32 + q] = records offered.
-template <int CH, bool SAMPLE>
-__global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const float* __restrict__ E, int64_t n_rows,
-                                                                const float* __restrict__ Qn, int64_t n_tiles,
+// BF16: E and Qn are bf16 (Qn prepared by prepare_queries_bf16); otherwise fp32.
+template <bool BF16, int CH, bool SAMPLE>
+__global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __restrict__ E, int64_t n_rows,
+                                                                const void* __restrict__ Qn, int64_t n_tiles,
                                                                 int64_t tile_stride, const float* __restrict__ thr,
                                                                 uint64_t* __restrict__ out, int64_t out_stride,
                                                                 uint32_t* __restrict__ cnt, int n_active) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  using G = DepthGeo<BF16>;
   constexpr int DIM = CH * kF32ChunkCols;
+  constexpr int RM = G::kRing - 1;                             // ring slot of chunk g: g & RM
   extern __shared__ __attribute__((aligned(16))) char lds[];   // ring | partial sums | per-query counters
-  float* const red = reinterpret_cast<float*>(lds + kF32Ring * kF32ChunkBytes);
-  uint32_t* const lcnt = reinterpret_cast<uint32_t*>(lds + kF32Ring * kF32ChunkBytes + kF32RedBytes);
+  float* const red = reinterpret_cast<float*>(lds + G::kRing * G::kChunk);
+  uint32_t* const lcnt = reinterpret_cast<uint32_t*>(lds + G::kRing * G::kChunk + kF32RedBytes);
 
   const int lane = lane_id();
   const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
   const int r = lane & 31, h = lane >> 5;
 
-  // ---- this wave's share of the queries (B operand): lane (r, h) holds Qn[r][256 ch + 32 w + 8 m + 4 h .. +3]
-  f32x4f qf[CH][4];
+  // ---- this wave's share of the queries (B operand), 16 bytes per read m: lane (r, h) holds
+  //      fp32: Qn[r][256 ch + 32 w + 8 m + 4 h .. +3]  (4 MFMAs)     bf16: Qn[r][256 ch + 32 w + 16 m + 8 h .. +7]  (1 MFMA)
+  u32x4f qf[CH][G::kReads];
 #pragma unroll
   for (int ch = 0; ch < CH; ++ch) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
-      qf[ch][m] = *reinterpret_cast<const f32x4f*>(Qn + static_cast<int64_t>(r) * DIM + kF32ChunkCols * ch + 32 * w + 8 * m + 4 * h);
+    for (int m = 0; m < G::kReads; ++m) {
+      const char* qrow = static_cast<const char*>(Qn) + static_cast<int64_t>(r) * DIM * G::kElem;
+      qf[ch][m] = *reinterpret_cast<const u32x4f*>(qrow + kF32ChunkCols * G::kElem * ch + 32 * G::kElem * w + 16 * (2 * m + h));
+    }
   }
   const float thr_l = SAMPLE ? -__builtin_inff() : (r < n_active ? thr[r] : __builtin_inff());
   // pin the waits for these loads here, before any DMA is in flight (a compiler-inserted vmcnt(0) inside the
@@ -94,16 +115,22 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const float* __r
 #pragma unroll
   for (int ch = 0; ch < CH; ++ch) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) asm volatile("" ::"v"(qf[ch][m]));
+    for (int m = 0; m < G::kReads; ++m) asm volatile("" ::"v"(qf[ch][m]));
   }
   asm volatile("" ::"v"(thr_l));
   if (!SAMPLE && threadIdx.x < kF32Queries) lcnt[threadIdx.x] = 0;   // read first at a tile end, behind several barriers
 
-  // ---- DMA: piece p of a chunk (p = 0..3) is row w + 8 p; its 16-byte unit u lands at LDS unit u ^ (row & 15),
-  // i.e. lane l (LDS unit l) fetches unit l ^ (row & 15).  row & 15 is w for p even and w + 8 for p odd.
-  const uint32_t row_bytes = DIM * 4;
-  const uint32_t voff_even = static_cast<uint32_t>(w) * row_bytes + 16u * static_cast<uint32_t>(lane ^ w);
-  const uint32_t voff_odd = static_cast<uint32_t>(w) * row_bytes + 16u * static_cast<uint32_t>(lane ^ (w + 8));
+  // ---- DMA.  The 16-byte unit u of a chunk row lands at LDS unit u ^ (row & 15), i.e. the lane that fills LDS
+  // unit u of that row fetches unit u ^ (row & 15).
+  //   fp32: piece p (0..3) of a wave is row w + 8 p (one row = 64 units); row & 15 is w for p even, w + 8 for p odd.
+  //   bf16: piece p (0..1) is rows 2 (w + 8 p) and + 1 (32 units each; lanes 32.. take the second row);
+  //         row & 15 = (2 w + lane / 32) & 15 for both pieces.
+  const uint32_t row_bytes = DIM * G::kElem;
+  const uint32_t row_b = static_cast<uint32_t>(2 * w + (lane >> 5));
+  const uint32_t voff_even = BF16 ? row_b * row_bytes + 16u * (static_cast<uint32_t>(lane & 31) ^ (row_b & 15u))
+                                  : static_cast<uint32_t>(w) * row_bytes + 16u * static_cast<uint32_t>(lane ^ w);
+  const uint32_t voff_odd = BF16 ? voff_even
+                                 : static_cast<uint32_t>(w) * row_bytes + 16u * static_cast<uint32_t>(lane ^ (w + 8));
   const char* Eb = reinterpret_cast<const char*>(E);
   const int64_t first = static_cast<int64_t>(blockIdx.x), step = static_cast<int64_t>(gridDim.x);
   const int64_t n_my = first < n_tiles ? (n_tiles - first + step - 1) / step : 0;
@@ -120,12 +147,12 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const float* __r
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Eb + row0 * row_bytes), 0, valid * static_cast<int>(row_bytes),
                                              0x00020000);
   };
-  // ---- A-fragment read addresses inside ring slot 0: row r, unit (8 w + 2 m + h) ^ (r & 15)
-  uint32_t a_addr[4];
+  // ---- A-fragment read addresses inside ring slot 0: row r, unit (units-per-wave * w + 2 m + h) ^ (r & 15)
+  uint32_t a_addr[G::kReads];
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int m = 0; m < G::kReads; ++m)
     a_addr[m] = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((LdsPtrF)(lds))) +
-                static_cast<uint32_t>(r * 1024 + 16 * ((8 * w + 2 * m + h) ^ (r & 15)));
+                static_cast<uint32_t>(r * G::kRowChunk + 16 * (((G::kRowChunk / 128) * w + 2 * m + h) ^ (r & 15)));
 
   // ---- Software pipeline.  Chunk sequence of this workgroup: g = it * CH + ch -> ring slot g & 3.  Iteration g
   //   waits for chunk g+1 (own pieces: vmcnt, everybody's: barrier), starts the LDS reads of chunk g+1, and
@@ -137,27 +164,28 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const float* __r
   //   iteration g.  Chunks past the last tile are fetched through an empty descriptor (zeros, no memory traffic)
   //   so that every iteration has the same 12 pieces outstanding at its vmcnt(8).
   auto issue_piece = [&](__amdgpu_buffer_rsrc_t rsrc, int ch, int slot, int p) {
-    char* base = lds + slot * kF32ChunkBytes + w * 1024;
+    char* base = lds + slot * G::kChunk + w * 1024;        // piece w + 8 p of the chunk's 1 KiB pieces
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtrF)(base + p * 8 * 1024), 16, (p & 1) ? voff_odd : voff_even,
-                                             p * 8 * static_cast<int>(row_bytes) + ch * 1024, 0, DEWI_F32MFMA_DMA_AUX);
+                                             p * (BF16 ? 16 : 8) * static_cast<int>(row_bytes) + ch * G::kRowChunk, 0,
+                                             DEWI_F32MFMA_DMA_AUX);
   };
   auto issue_g = [&](int64_t g) {   // run-time chunk index (prologue only)
     const int64_t it = g / CH;
     const int ch = static_cast<int>(g - it * CH);
     const __amdgpu_buffer_rsrc_t rs = tile_rsrc(it);
-    const int slot = static_cast<int>(g & 3);
+    const int slot = static_cast<int>(g & RM);
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       if (ch == c) {
 #pragma unroll
-        for (int p = 0; p < kF32PiecesPerWave; ++p) issue_piece(rs, c, slot, p);
+        for (int p = 0; p < G::kPieces; ++p) issue_piece(rs, c, slot, p);
       }
     }
   };
-  auto read_chunk = [&](f32x4f (&dst)[4], int slot) {
-    const uint32_t slot_off = static_cast<uint32_t>(slot) * kF32ChunkBytes;
+  auto read_chunk = [&](u32x4f (&dst)[G::kReads], int slot) {
+    const uint32_t slot_off = static_cast<uint32_t>(slot) * G::kChunk;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) asm volatile("ds_read_b128 %0, %1" : "=v"(dst[m]) : "v"(a_addr[m] + slot_off));
+    for (int m = 0; m < G::kReads; ++m) asm volatile("ds_read_b128 %0, %1" : "=v"(dst[m]) : "v"(a_addr[m] + slot_off));
   };
   // partial sums: wave v keeps register j at red[(v * 15 + slot_of(j, v)) * 64 + lane]; its own two registers go
   // to the spare slot 14 (never read), which keeps the stores free of branches
@@ -231,18 +259,22 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const float* __r
     }
   };
 
-  f32x4f cur[4], nxt[4];
+  u32x4f cur[G::kReads], nxt[G::kReads];
   f32x16f acc;
+  auto reads_done = [&](u32x4f (&f)[G::kReads]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int m = 0; m < G::kReads; ++m) asm volatile("" : "+v"(f[m]));
+  };
   if (n_my > 0) {
-    issue_g(0);
-    issue_g(1);
-    issue_g(2);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // own pieces of chunk 0
+#pragma unroll
+    for (int g0 = 0; g0 < G::kRing - 1; ++g0) issue_g(g0);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::kWaitPieces) : "memory");        // own pieces of chunk 0
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    issue_g(3);
+    issue_g(G::kRing - 1);
     read_chunk(cur, 0);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
+    reads_done(cur);
   }
   for (int64_t it = 0; it < n_my; ++it) {
 #pragma unroll
@@ -251,36 +283,43 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const float* __r
       // own pieces of chunk g+1 have landed: of the 12 pieces outstanding (chunks g+1, g+2, g+3) all but the 8
       // youngest are done (vector-memory operations retire in issue order; a survivor store in between only makes
       // the wait stricter)
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::kWaitPieces) : "memory");
       // one barrier per chunk: every wave's pieces of chunk g+1 are in LDS, every wave has finished reading chunk g
       // (its slot is refilled below), and — first chunk of a tile — the partial sums of the previous tile are in LDS
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      read_chunk(nxt, static_cast<int>((g + 1) & 3));
+      read_chunk(nxt, static_cast<int>((g + 1) & RM));
       const bool finish_prev = ch == 0 && it > 0;      // the previous tile's partials were stored before this barrier
       if (finish_prev) stage2_load();
-      const __amdgpu_buffer_rsrc_t rs4 = tile_rsrc(it + (ch + 4) / CH);
+      const __amdgpu_buffer_rsrc_t rs4 = tile_rsrc(it + (ch + G::kRing) / CH);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
+      for (int m = 0; m < G::kReads; ++m) {
+        const f32x16f zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if constexpr (BF16) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8f, cur[m]), __builtin_bit_cast(bf16x8f, qf[ch][m]),
+                                                        (ch == 0 && m == 0) ? zero : acc, 0, 0, 0);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const f32x16f zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[m][i], qf[ch][m][i], (ch == 0 && m == 0 && i == 0) ? zero : acc, 0, 0, 0);
+          for (int i = 0; i < 4; ++i) {
+            const uint32_t au = cur[m][i], qu = qf[ch][m][i];    // copy the lane to a scalar before the bit cast
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, au), __builtin_bit_cast(float, qu),
+                                                       (ch == 0 && m == 0 && i == 0) ? zero : acc, 0, 0, 0);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
-        issue_piece(rs4, (ch + 4) % CH, static_cast<int>((g + 4) & 3), m);
+        issue_piece(rs4, (ch + G::kRing) % CH, static_cast<int>((g + G::kRing) & RM), m);   // kPieces == kReads
         __builtin_amdgcn_sched_barrier(0);
       }
       // chunk g+1's fragments (and the previous tile's partials) are in registers
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]));
+      reads_done(nxt);
       if (finish_prev) {
 #pragma unroll
         for (int v = 0; v < kF32Waves; ++v) asm volatile("" : "+v"(part[v][0]), "+v"(part[v][1]));
         stage2_finish(it - 1);
       }
 #pragma unroll
-      for (int m = 0; m < 4; ++m) cur[m] = nxt[m];
+      for (int m = 0; m < G::kReads; ++m) cur[m] = nxt[m];
       if (ch == CH - 1) {
         // the tile's block is complete in this wave's depth slice: hand the partials over.  With one chunk per tile
         // the other waves may still be reading the previous tile's partials (no barrier since): wait for them.
@@ -318,13 +357,14 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const float* __r
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-bool mfma_f32_path_supported(int64_t n_rows, int dim, int n_queries, int n_candidates, int space) {
+bool mfma_f32_path_supported(int elem_type, int64_t n_rows, int dim, int n_queries, int n_candidates, int space) {
   const int ch = dim / kF32ChunkCols;
-  return space == DEWI_SPACE_COSINE && n_queries >= kMfmaF32MinQueries && dim % kF32ChunkCols == 0 && ch >= 1 && ch <= 6 &&
-         ch != 5 && n_rows >= 64 * 1024 && n_candidates <= 256;
+  const int min_q = elem_type ? kMfmaMinQueries : kMfmaF32MinQueries;
+  return space == DEWI_SPACE_COSINE && n_queries >= min_q && dim % kF32ChunkCols == 0 && ch >= 1 && ch <= 6 && ch != 5 &&
+         n_rows >= 64 * 1024 && n_candidates <= 256;
 }
 
-MfmaF32Layout plan_mfma_f32(int64_t n_rows, int dim, int n_queries, int n_candidates, int compute_units) {
+MfmaF32Layout plan_mfma_f32(int elem_type, int64_t n_rows, int dim, int n_queries, int n_candidates, int compute_units) {
   MfmaF32Layout m{};
   auto up = [](size_t v) { return (v + 255) / 256 * 256; };
   m.groups = (n_queries + kF32Queries - 1) / kF32Queries;
@@ -346,7 +386,7 @@ MfmaF32Layout plan_mfma_f32(int64_t n_rows, int dim, int n_queries, int n_candid
   int64_t cap = (8 * stride * n_candidates + m.n_seg - 1) / m.n_seg;
   m.seg_cap = static_cast<int>(cap < 16 ? 16 : cap);
   size_t off = 0;
-  m.qn_off = off;      off += up(static_cast<size_t>(m.q_pad) * dim * 4);
+  m.qn_off = off;      off += up(static_cast<size_t>(m.q_pad) * dim * (elem_type ? 2 : 4));
   m.thr_off = off;     off += up(static_cast<size_t>(m.q_pad) * 4);
   m.cnt_off = off;     off += up(static_cast<size_t>(m.groups) * m.n_seg * kF32Queries * 4);
   m.dense_off = off;   off += up(static_cast<size_t>(kF32Queries) * m.sample_stride * 4);
@@ -355,40 +395,41 @@ MfmaF32Layout plan_mfma_f32(int64_t n_rows, int dim, int n_queries, int n_candid
   return m;
 }
 
-template <int CH>
-static hipError_t run_mfma_f32_dim(const MfmaF32Layout& m, const float* E, int64_t n_rows, int n_queries, int n_candidates,
+template <bool BF16, int CH>
+static hipError_t run_mfma_f32_dim(const MfmaF32Layout& m, const void* E, int64_t n_rows, int n_queries, int n_candidates,
                                    char* ws, hipStream_t stream) {
   constexpr int DIM = CH * kF32ChunkCols;
-  static PerDeviceOnce attr_once;   // one per CH instantiation
+  constexpr int kLds = depth_lds_bytes<BF16>();
+  static PerDeviceOnce attr_once;   // one per instantiation
   const hipError_t ea = attr_once.run([] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan_f32<CH, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kF32LdsBytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan_f32<BF16, CH, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan_f32<CH, false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kF32LdsBytes);
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan_f32<BF16, CH, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
   });
   if (ea != hipSuccess) return ea;
-  const float* qn = reinterpret_cast<const float*>(ws + m.qn_off);
+  const char* qn = ws + m.qn_off;
   float* thr = reinterpret_cast<float*>(ws + m.thr_off);
   uint32_t* cnt = reinterpret_cast<uint32_t*>(ws + m.cnt_off);
   float* dense = reinterpret_cast<float*>(ws + m.dense_off);
   uint64_t* cand = reinterpret_cast<uint64_t*>(ws + m.cand_off);
   for (int g = 0; g < m.groups; ++g) {
-    const float* qg = qn + static_cast<int64_t>(g) * kF32Queries * DIM;
+    const void* qg = qn + static_cast<int64_t>(g) * kF32Queries * DIM * (BF16 ? 2 : 4);
     float* tg = thr + g * kF32Queries;
     uint32_t* cg = cnt + static_cast<int64_t>(g) * m.n_seg * kF32Queries;
     uint64_t* og = cand + static_cast<int64_t>(g) * m.n_seg * kF32Queries * m.seg_cap;
     const int n_active = n_queries - g * kF32Queries < kF32Queries ? n_queries - g * kF32Queries : kF32Queries;
     // 1. group maxima over the strided sample
-    hipLaunchKernelGGL((mfma_scan_f32<CH, true>), dim3(m.sample_blocks), dim3(kF32Threads), kF32LdsBytes, stream, E, n_rows, qg,
+    hipLaunchKernelGGL((mfma_scan_f32<BF16, CH, true>), dim3(m.sample_blocks), dim3(kF32Threads), kLds, stream, E, n_rows, qg,
                        m.n_sample_tiles, m.tile_stride, static_cast<const float*>(nullptr), reinterpret_cast<uint64_t*>(dense),
                        m.sample_stride, static_cast<uint32_t*>(nullptr), n_active);
     // 2. per-query threshold: the c-th largest group maximum (real queries only)
     const hipError_t et = launch_sample_threshold(dense, m.sample_stride, m.sample_stride, n_candidates, tg, n_active, stream);
     if (et != hipSuccess) return et;
-    // 3. the full pass with the filter (the kernel dewi_timing_read reports: algorithmic bytes = n_rows * dim * 4)
+    // 3. the full pass with the filter (the kernel dewi_timing_read reports: algorithmic bytes = n_rows * dim * elem)
     timing_begin(stream);
-    hipLaunchKernelGGL((mfma_scan_f32<CH, false>), dim3(m.n_blocks), dim3(kF32Threads), kF32LdsBytes, stream, E, n_rows, qg,
+    hipLaunchKernelGGL((mfma_scan_f32<BF16, CH, false>), dim3(m.n_blocks), dim3(kF32Threads), kLds, stream, E, n_rows, qg,
                        m.n_tiles, static_cast<int64_t>(1), static_cast<const float*>(tg), og, static_cast<int64_t>(m.seg_cap), cg,
                        n_active);
     timing_end(stream);
@@ -396,20 +437,28 @@ static hipError_t run_mfma_f32_dim(const MfmaF32Layout& m, const float* E, int64
   return hipGetLastError();
 }
 
-hipError_t launch_mfma_f32(const MfmaF32Layout& m, const float* d_E, int64_t n_rows, int dim, const float* d_Q, int n_queries,
-                           int n_candidates, int space, char* ws, hipStream_t stream) {
-  // normalised fp32 queries, zero rows behind the real ones (a padding query scores 0 everywhere; its threshold
-  // is forced to +inf in the kernel)
-  hipError_t e = launch_prepare_queries_padded(d_Q, reinterpret_cast<float*>(ws + m.qn_off), n_queries, m.q_pad, dim, space, stream);
+hipError_t launch_mfma_f32(const MfmaF32Layout& m, int elem_type, const void* d_E, int64_t n_rows, int dim, const float* d_Q,
+                           int n_queries, int n_candidates, int space, char* ws, hipStream_t stream) {
+  // normalised queries (fp32, or rounded to bf16 for a bf16 corpus), zero rows behind the real ones (a padding query
+  // scores 0 everywhere; its threshold is forced to +inf in the kernel)
+  hipError_t e = elem_type ? launch_prepare_queries_bf16(d_Q, reinterpret_cast<uint16_t*>(ws + m.qn_off), n_queries, m.q_pad, dim,
+                                                         space, stream)
+                           : launch_prepare_queries_padded(d_Q, reinterpret_cast<float*>(ws + m.qn_off), n_queries, m.q_pad, dim,
+                                                           space, stream);
   if (e != hipSuccess) return e;
+#define DEWI_DEPTH(CH)                                                                                            \
+  case CH:                                                                                                        \
+    return elem_type ? run_mfma_f32_dim<true, CH>(m, d_E, n_rows, n_queries, n_candidates, ws, stream)            \
+                     : run_mfma_f32_dim<false, CH>(m, d_E, n_rows, n_queries, n_candidates, ws, stream);
   switch (dim / kF32ChunkCols) {
-    case 1: return run_mfma_f32_dim<1>(m, d_E, n_rows, n_queries, n_candidates, ws, stream);
-    case 2: return run_mfma_f32_dim<2>(m, d_E, n_rows, n_queries, n_candidates, ws, stream);
-    case 3: return run_mfma_f32_dim<3>(m, d_E, n_rows, n_queries, n_candidates, ws, stream);
-    case 4: return run_mfma_f32_dim<4>(m, d_E, n_rows, n_queries, n_candidates, ws, stream);
-    case 6: return run_mfma_f32_dim<6>(m, d_E, n_rows, n_queries, n_candidates, ws, stream);
+    DEWI_DEPTH(1)
+    DEWI_DEPTH(2)
+    DEWI_DEPTH(3)
+    DEWI_DEPTH(4)
+    DEWI_DEPTH(6)
     default: return hipErrorInvalidValue;
   }
+#undef DEWI_DEPTH
 }
 
 }  // namespace dewi

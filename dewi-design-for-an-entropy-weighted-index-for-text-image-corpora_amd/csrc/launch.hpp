@@ -132,10 +132,13 @@ struct MfmaF32Layout {
   int seg_cap;             // records per (workgroup, query) segment
   size_t qn_off, thr_off, cnt_off, dense_off, cand_off, total;
 };
-bool mfma_f32_path_supported(int64_t n_rows, int dim, int n_queries, int n_candidates, int space);
-MfmaF32Layout plan_mfma_f32(int64_t n_rows, int dim, int n_queries, int n_candidates, int compute_units);
-hipError_t launch_mfma_f32(const MfmaF32Layout& m, const float* d_E, int64_t n_rows, int dim, const float* d_Q, int n_queries,
-                           int n_candidates, int space, char* ws, hipStream_t stream);
+// elem_type 0: fp32 corpus (>= kMfmaF32MinQueries queries); 1: bf16 corpus (>= kMfmaMinQueries queries: the same
+// depth-split kernel on 32x32x16 bf16 MFMAs — batches of up to 32 queries at the tile-delivery rate, and the
+// dimensions the 256-query kernel of knn_mfma_bf16.hip cannot hold in registers: 1024, 1536)
+bool mfma_f32_path_supported(int elem_type, int64_t n_rows, int dim, int n_queries, int n_candidates, int space);
+MfmaF32Layout plan_mfma_f32(int elem_type, int64_t n_rows, int dim, int n_queries, int n_candidates, int compute_units);
+hipError_t launch_mfma_f32(const MfmaF32Layout& m, int elem_type, const void* d_E, int64_t n_rows, int dim, const float* d_Q,
+                           int n_queries, int n_candidates, int space, char* ws, hipStream_t stream);
 
 // Per-query threshold = the n_candidates-th largest of each query's sample values (knn_mfma_bf16.hip).
 hipError_t launch_sample_threshold(const float* dense, int64_t n_sample, int64_t stride, int n_candidates, float* thr,

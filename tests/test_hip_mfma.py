@@ -35,9 +35,11 @@ def _corpus(n, dim, seed, space="cosine"):
 
 
 @pytest.mark.parametrize("dim,n,b,k", [(768, 70_001, 256, 100), (768, 66_000, 40, 10), (512, 80_000, 300, 10),
-                                       (256, 70_000, 17, 100), (128, 131_072, 64, 10),
-                                       (128, 1_100_000, 32, 10)])   # > 32 K sample scores per query: thresholds
-                                                                    # from global memory instead of LDS
+                                       (256, 70_000, 17, 100), (128, 131_072, 64, 10), (128, 1_100_000, 32, 10),
+                                       # up to 32 queries, and dimensions the 256-query kernel cannot hold in
+                                       # registers: the depth-split pass (csrc/knn_mfma_f32.hip, bf16 geometry)
+                                       (768, 70_001, 8, 10), (768, 70_001, 32, 100), (512, 80_000, 2, 10),
+                                       (1024, 65_600, 70, 10), (1536, 66_000, 40, 10)])
 def test_mfma_batched_vs_oracle(dim, n, b, k):
     import torch
     cb, Eb, dewi32, ent32 = _corpus(n, dim, seed=dim + b)
