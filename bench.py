@@ -165,6 +165,23 @@ def best_blas_threads(fn):
     return min(probe, key=probe.get), probe, avail
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on STDOUT when its first communicator comes up; the contract of this script
+    is ONE JSON line on stdout, so file descriptor 1 points at stderr while the process group is brought up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def oracle_imports():
     sys.path.insert(0, str(REPO / "oracle"))
     sys.path.insert(0, str(REPO / "tests"))
@@ -217,7 +234,9 @@ def run_c2(args, torch, dist, eng, nat, rank, world, device):
     if force_dist and world == 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=device)
+        with stdout_to_stderr():
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=device)
+            dist.barrier()                                   # brings the communicator (and RCCL's banner) up here
     sharded = world > 1 or force_dist
     # Single GPU: queries back to back on ONE stream (scan, select; next query).  Overlapping the select
     # of query i with the scan of query i+1 on a second stream (DEWI_BENCH_PIPELINE=1) was measured
@@ -863,7 +882,9 @@ def main():
     device = torch.device(f"cuda:{local_rank}")
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=device)
+        with stdout_to_stderr():
+            dist.init_process_group(backend="nccl", device_id=device)
+            dist.barrier()                                   # brings the communicator (and RCCL's banner) up here
 
     from dewi import _engine as eng
     from dewi import _native as nat
