@@ -7,8 +7,9 @@ numbers are comparable with anything measured through the reference script:
 
 metrics.json: {"build": {n_docs, dim, data_generation_time, index_construction_time, docs_per_second},
                "search": {n_queries, k, total_search_time, queries_per_second, latency_ms}}
-`--per-row-add` builds with one DewiIndex.add call per document as the reference script does (Python-bound);
-the default is the bulk add_batch.  Searches go one query at a time through DewiIndex.search (host query in,
+`--per-row-add` builds with one DewiIndex.add call per document as the reference script does (Python-bound),
+`--objects` with the bulk add_batch of Payload objects; the default is add_batch_columns (payloads as arrays:
+no Python object per document; Payload objects are made for the rows a search returns).  Searches go one query at a time through DewiIndex.search (host query in,
 [(doc_id, score, Payload)] out), like the reference's loop.
 """
 import argparse
@@ -23,7 +24,7 @@ REPO = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(REPO / "dewi-design-for-an-entropy-weighted-index-for-text-image-corpora_amd"))
 
 
-def synthetic_corpus(n_docs, dim, seed=42):
+def synthetic_corpus(n_docs, dim, seed=42, objects=True):
     """Distributions of the reference harness: unit-norm Gaussian rows, Beta / Gamma signals."""
     from dewi.types import Payload
     rng = np.random.RandomState(seed)
@@ -36,18 +37,20 @@ def synthetic_corpus(n_docs, dim, seed=42):
         "hi_q90": 1.5 * rng.gamma(2, 0.3, n_docs), "I_hat": rng.beta(2, 2, n_docs),
         "redundancy": rng.beta(1, 5, n_docs), "noise": rng.beta(1, 10, n_docs),
     }
-    payloads = [Payload(**{k: float(v[i]) for k, v in cols.items()}) for i in range(n_docs)]
+    payloads = [Payload(**{k: float(v[i]) for k, v in cols.items()}) for i in range(n_docs)] if objects else cols
     return ids, emb, payloads
 
 
-def build(ids, emb, payloads, per_row):
+def build(ids, emb, payloads, mode):
     from dewi.index import DewiIndex
     index = DewiIndex(dim=emb.shape[1], use_ann=False, rerank_eta=0.3)
-    if per_row:
+    if mode == "per_row":
         for i, doc_id in enumerate(ids):
             index.add(doc_id, emb[i], payloads[i])
-    else:
+    elif mode == "objects":
         index.add_batch(ids, emb, payloads)
+    else:
+        index.add_batch_columns(ids, emb, payloads)
     index.build()
     return index
 
@@ -62,20 +65,23 @@ def main():
     ap.add_argument("--skip-build", action="store_true")
     ap.add_argument("--skip-search", action="store_true")
     ap.add_argument("--per-row-add", action="store_true", help="one add() per document, as the reference script")
+    ap.add_argument("--objects", action="store_true", help="bulk add_batch of Payload objects instead of columns")
     a = ap.parse_args()
     out_dir = Path(a.output)
     out_dir.mkdir(parents=True, exist_ok=True)
     metrics = {}
 
     t0 = time.time()
-    ids, emb, payloads = synthetic_corpus(a.n_docs, a.dim)
+    mode = "per_row" if a.per_row_add else ("objects" if a.objects else "columns")
+    ids, emb, payloads = synthetic_corpus(a.n_docs, a.dim, objects=mode != "columns")
     gen_time = time.time() - t0
     t0 = time.time()
-    index = build(ids, emb, payloads, a.per_row_add)
+    index = build(ids, emb, payloads, mode)
     build_time = time.time() - t0
     if not a.skip_build:
         metrics["build"] = {"n_docs": a.n_docs, "dim": a.dim, "data_generation_time": gen_time,
-                            "index_construction_time": build_time, "docs_per_second": a.n_docs / build_time}
+                            "index_construction_time": build_time, "docs_per_second": a.n_docs / build_time,
+                            "ingest": mode}
     if not a.skip_search:
         rng = np.random.RandomState(7)
         queries = rng.randn(a.n_queries, a.dim).astype(np.float32)

@@ -49,6 +49,11 @@ def test_c2_properties_and_oracle_sample(corpus_1m):
     assert (ids_b == ids).float().mean().item() > 0.99 and torch.allclose(sc_b, sc, rtol=0, atol=2e-6)
     ids_again, sc_again = c.search_device(Q, k, eta, 0.0)                       # deterministic
     assert torch.equal(ids_again, ids_b) and torch.equal(sc_again, sc_b)
+    E_host = c.emb.cpu().numpy()
+    Qb_h, ib_h, sb_h = Q.cpu().numpy(), ids_b.cpu().numpy(), sc_b.cpu().numpy()
+    for j in range(32, 40):                                                      # the matrix-core pass vs the oracle
+        decisive, msg = compare_query(E_host, Qb_h[j], dewi32, ent32, k, eta, 0.0, "cosine", ib_h[j], sb_h[j], exact_gaps=False)
+        assert msg is None, (j, msg)
     # shard-independence: 3 ragged shards (views of the same matrix) + merge == whole
     bounds = [0, 333_333, 700_001, c.n_rows]
     lists = []
@@ -59,7 +64,7 @@ def test_c2_properties_and_oracle_sample(corpus_1m):
     m_ids, m_sc = eng.merge_rerank_device(torch.stack(lists), 2 * k, k, eta, 0.0)
     assert torch.equal(m_ids, ids_b) and torch.equal(m_sc, sc_b)      # same per-row sums whichever shard holds the row
     # the oracle on 8 of the queries
-    E = c.emb.cpu().numpy()
+    E = E_host
     Qh, ih, sh_ = Q.cpu().numpy(), ids.cpu().numpy(), sc.cpu().numpy()
     for j in range(8):
         decisive, msg = compare_query(E, Qh[j], dewi32, ent32, k, eta, 0.0, "cosine", ih[j], sh_[j], exact_gaps=False)
