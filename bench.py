@@ -580,7 +580,7 @@ def run_c3(args, torch, eng, nat, device):
     flops = 2.0 * B * n * dim
     hbm = algo_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     tf = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
-    kernel = "mfma_scan_bf16<48,false>"
+    kernel = "mfma_scan_bf16_s16<48,false>"
     traffic, traffic_note = recorded_traffic(f"{n}x{dim}x2xB{B}", kernel)
     result = {
         "metric": "queries/sec, 1M×768 bf16 corpus, query batch=256, k=100, η=0.3 (BASELINE.json configs[2])",

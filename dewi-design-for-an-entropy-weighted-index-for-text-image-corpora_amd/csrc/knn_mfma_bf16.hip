@@ -96,6 +96,11 @@ constexpr int kTileBufs = 3;          // LDS ring: the tile being multiplied + t
 #ifndef DEWI_MFMA_PRIO
 #define DEWI_MFMA_PRIO 1
 #endif
+#ifndef DEWI_MFMA_SHAPE16
+#define DEWI_MFMA_SHAPE16 1   // 1: mfma_scan_bf16_s16 (v_mfma_f32_16x16x32_bf16), 0: mfma_scan_bf16 (32x32x16)
+#endif
+constexpr bool kShape16 = DEWI_MFMA_SHAPE16 != 0;
+constexpr int kSegPerBlock = kShape16 ? 4 : 2;   // lane-private survivor segments per workgroup and query
 #ifndef DEWI_MFMA_ABLATE
 #define DEWI_MFMA_ABLATE 0   // timing experiments only: 1 no epilogue, 2 no DMA after the first tile, 3 no MFMA
 #endif
@@ -526,6 +531,302 @@ __global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same pass on v_mfma_f32_16x16x32_bf16 (round 2).  Equal FLOPs, LDS bytes and matrix-pipe cycles per tile —
+// per 32 columns four 16-cycle MFMAs (2 document halves x 2 query halves) instead of two 32-cycle ones — but the
+// chip holds a HIGHER CLOCK on this shape in a power-limited loop (MI355X_MICROARCH.md, DVFS give-back item 7;
+// cdna_hip_programming.md §5.4 rule 28): timing experiment with the operands of the 32x32 kernel pushed through
+// 16x16x32 instructions 282-310 us against 336.  Same structure as mfma_scan_bf16 (queries in registers, tile ring by
+// LDS-DMA with the XOR swizzle, matrix block / side phase halves of the two waves of a SIMD, lane-private survivor
+// segments); what changes is the fragment geometry:
+//   lane l = (c = l & 15, g = l >> 4).  k-step s covers columns 32 s .. 32 s + 31; lane group g holds columns 32 s + 8 g .. +7.
+//   B (queries, registers): qf[qh][s] = Qb[32 wave + 16 qh + c][32 s + 8 g .. +7], qh = 0, 1        (2 x 24 x 4 = 192 VGPRs at dim 768)
+//   A (documents, LDS):     fragment f = 2 s + dh = rows 16 dh + c of the tile, 16-byte unit 4 s + g, swizzled as the DMA
+//                           wrote it: unit (u & ~15) | ((u & 15) ^ (row & 15)) — still conflict-free for the 4 x 16-lane
+//                           groups of ds_read_b128 (rows {0-3, 12-15} of group g with rows {4-11} of group g+1).
+//   D:                      acc[dh][qh][t] = score of document 16 dh + 4 g + t against query 32 wave + 16 qh + c.
+// A lane therefore holds TWO queries (qh = 0, 1) with eight documents each; a query belongs to four lanes (g = 0..3) of
+// one wave: quarter-segments, segment index 4 blockIdx.x + g, two slot counters per lane.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+
+template <int KS, bool DENSE>   // KS = dim / 16 as for mfma_scan_bf16 (dim % 128 == 0, dim <= 768)
+__global__ __launch_bounds__(512, 2) void mfma_scan_bf16_s16(
+    const uint16_t* __restrict__ E, int64_t n_rows, const uint16_t* __restrict__ Qb, int64_t n_tiles,
+    int64_t tile_stride, const float* __restrict__ thr, uint64_t* __restrict__ out, int64_t out_stride,
+    uint32_t* __restrict__ cnt, int n_active) {
+  // DENSE (sample pass): out is a float array: out[q * out_stride + (4 * blockIdx.x + g) * 8 + 4 dh + t] = the best score
+  //        that accumulator register saw over this workgroup's (strided) tiles — 32 group maxima per workgroup and query.
+  // filter: raw records out[((4 * blockIdx.x + g) * 256 + q) * out_stride + slot], cnt[(4 * blockIdx.x + g) * 256 + q].
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int DIM = KS * 16;
+  constexpr int KS2 = KS / 2;                      // 32-column k-steps
+  constexpr int NF = KS;                           // A fragments per tile (2 per k-step)
+  constexpr int UPR = DIM / 8;                     // 16-byte units per row
+  constexpr int TILE_BYTES = kTileRows * DIM * 2;
+  constexpr int PIECES = TILE_BYTES / 1024;
+  constexpr int NW = 8;
+  constexpr int PPW = PIECES / NW;
+  static_assert(KS % 8 == 0 && KS <= 48, "dim must be a multiple of 128, at most 768");
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // kTileBufs x TILE_BYTES
+
+  const int lane = lane_id();
+  const int wave = static_cast<int>(threadIdx.x) >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const bool active = 32 * wave_u < n_active;
+
+  bf16x8 qf[2][KS2];
+#pragma unroll
+  for (int qh = 0; qh < 2; ++qh) {
+    const bf16x8* qp = reinterpret_cast<const bf16x8*>(Qb + static_cast<int64_t>(32 * wave + 16 * qh + c) * DIM + 8 * g);
+#pragma unroll
+    for (int s = 0; s < KS2; ++s) qf[qh][s] = qp[active ? 4 * s : 0];
+  }
+  float thr_l[2];
+#pragma unroll
+  for (int qh = 0; qh < 2; ++qh) {
+    const int q = 32 * wave + 16 * qh + c;
+    thr_l[qh] = DENSE ? -__builtin_inff() : (q < n_active ? thr[q] : __builtin_inff());
+  }
+#pragma unroll
+  for (int s = 0; s < KS2; ++s) {
+    asm volatile("" ::"v"(qf[0][s]));
+    asm volatile("" ::"v"(qf[1][s]));
+  }
+  asm volatile("" ::"v"(thr_l[0]), "v"(thr_l[1]));
+
+  // ---- DMA source offsets: as in mfma_scan_bf16 (the LDS image of a tile is the same)
+  constexpr int VO = (KS % (2 * NW) == 0) ? KS / (2 * NW) : PPW;
+  uint32_t voff[VO];
+#pragma unroll
+  for (int i = 0; i < VO; ++i) {
+    const int piece = i * NW + wave;
+    const int x = piece * 64 + lane;
+    const int row = x / UPR, cp = x % UPR;
+    const int cc = (cp & ~15) | ((cp & 15) ^ (row & 15));
+    voff[i] = static_cast<uint32_t>(row * (DIM * 2) + cc * 16);
+  }
+  // ---- A-fragment read addresses: row c (+ 16 dh as an immediate), unit 4 s + g -> low four bits 4 (s & 3) + g, XOR c
+  uint32_t a_addr[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    a_addr[j] = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((LdsPtr)(lds))) +
+                static_cast<uint32_t>(c * UPR * 16 + 16 * ((4 * j + g) ^ c));
+
+  const char* Eb = reinterpret_cast<const char*>(E);
+  auto tile_rsrc = [&](int64_t tile_index) {
+    const int64_t row0 = tile_index * kTileRows;
+    const int64_t left = n_rows - row0;
+    const int valid_rows = left < kTileRows ? static_cast<int>(left) : kTileRows;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Eb + row0 * (DIM * 2)), 0, valid_rows * (DIM * 2),
+                                             0x00020000);
+  };
+  auto issue_piece = [&](__amdgpu_buffer_rsrc_t rsrc, int buf, int i) {
+    char* l = lds + buf * TILE_BYTES + (i * NW + wave_u) * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)(l), 16, voff[i % VO], (i / VO) * (16 * DIM * 2), 0, DEWI_MFMA_DMA_AUX);
+  };
+
+  // ---- survivor quarter-segments: byte offset of the next free record, one per query half
+  uint32_t off[2];
+#pragma unroll
+  for (int qh = 0; qh < 2; ++qh)
+    off[qh] = ((static_cast<uint32_t>(blockIdx.x) * 4 + g) * kQueriesPerPass + (32 * wave + 16 * qh + c)) *
+              static_cast<uint32_t>(out_stride) * 8u;
+
+  const int64_t first = static_cast<int64_t>(blockIdx.x);
+  const int64_t step = static_cast<int64_t>(gridDim.x);
+  if (first < n_tiles) {
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(first * tile_stride);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) issue_piece(rs, 0, i);
+  }
+  if (first + step < n_tiles) {
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc((first + step) * tile_stride);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) issue_piece(rs, 1, i);
+  }
+  const uint64_t out_bits = reinterpret_cast<uint64_t>(out);
+  uint64_t* const out_uniform = reinterpret_cast<uint64_t*>(
+      (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(out_bits >> 32)))) << 32) |
+      static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(out_bits))));
+
+  float mx[DENSE ? 2 : 1][8];
+  if constexpr (DENSE) {
+#pragma unroll
+    for (int qh = 0; qh < 2; ++qh) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) mx[qh][j] = -__builtin_inff();
+    }
+  }
+  // The epilogue of tile i.  acc[dh][qh][t]: document row0 + 16 dh + 4 g + t, query 32 wave + 16 qh + c.
+  auto epilogue = [&](f32x4a (&acc)[2][2], int64_t i) {
+    const int64_t row0 = i * tile_stride * kTileRows;
+    const int doc0 = static_cast<int>(row0) + 4 * g;
+    if (row0 + kTileRows > n_rows) {                           // partial last tile: padding rows never pass
+#pragma unroll
+      for (int dh = 0; dh < 2; ++dh) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (row0 + 16 * dh + 4 * g + t >= n_rows) {
+            acc[dh][0][t] = -__builtin_inff();
+            acc[dh][1][t] = -__builtin_inff();
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int qh = 0; qh < 2; ++qh) {
+      // the eight scores of this lane for query half qh, in document order: j = 4 dh + t -> row offset 16 dh + t.
+      // One compaction chain and one predicated store per query half: a single 16-register chain with a selected
+      // threshold / segment per register measured slower (more second rounds, more vector instructions): 0.975 vs
+      // 0.957 of the 32x32x16 kernel's time.
+#define sc_(j) acc[(j) >> 2][qh][(j) & 3]
+      if constexpr (DENSE) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mx[qh][j] = __builtin_fmaxf(mx[qh][j], sc_(j));
+      } else {
+        const uint32_t seg_q = (static_cast<uint32_t>(blockIdx.x) * 4 + g) * kQueriesPerPass + (32 * wave + 16 * qh + c);
+        const uint32_t end_bytes = (seg_q + 1u) * static_cast<uint32_t>(out_stride) * 8u;
+        const bool tight = off[qh] + 8u * 8u > end_bytes;   // also true once the segment has overflowed
+        if (__builtin_amdgcn_ballot_w64(tight) == 0ull) {
+          auto store_where = [&](uint32_t flag, uint32_t row_off, float score) {
+            const uint64_t rec = (static_cast<uint64_t>(static_cast<uint32_t>(doc0) + row_off) << 32) | __float_as_uint(score);
+            uint64_t saved_exec;
+            asm volatile(
+                "v_cmp_ne_u32 vcc, 0, %[f]\n\t"
+                "s_and_saveexec_b64 %[sv], vcc\n\t"
+                "global_store_dwordx2 %[off], %[rec], %[base]\n\t"
+                "v_add_u32 %[off], 8, %[off]\n\t"
+                "s_mov_b64 exec, %[sv]"
+                : [off] "+v"(off[qh]), [sv] "=&s"(saved_exec)
+                : [f] "v"(flag), [rec] "v"(rec), [base] "s"(out_uniform)
+                : "vcc", "memory");
+          };
+          uint32_t mask = 0;
+          float firstv = 0.f;
+#pragma unroll
+          for (int j = 7; j >= 0; --j) {
+            const bool pass = !(sc_(j) < thr_l[qh]);            // NaN passes (NumPy ranks NaN first)
+            firstv = pass ? sc_(j) : firstv;
+            mask = mask + mask + (pass ? 1u : 0u);
+          }
+          uint32_t n_pass = static_cast<uint32_t>(__builtin_popcount(mask));
+          const uint32_t j0 = static_cast<uint32_t>(__builtin_ctz(mask | 0x100u));   // first passing register (8: none)
+          uint32_t ro = (j0 & 3u) + 16u * (j0 >> 2);
+          store_where(n_pass, ro, firstv);
+          uint32_t more = n_pass > 1u ? 1u : 0u;
+          while (__builtin_amdgcn_ballot_w64(more != 0u) != 0ull) {
+            uint32_t ro_next = 0;
+            float next = 0.f;
+#pragma unroll
+            for (int j = 7; j >= 1; --j) {
+              const uint32_t roj = static_cast<uint32_t>((j & 3) + 16 * (j >> 2));
+              const bool pass = !(sc_(j) < thr_l[qh]) && roj > ro;
+              next = pass ? sc_(j) : next;
+              ro_next = pass ? roj : ro_next;
+            }
+            store_where(more, ro_next, next);
+            ro = more ? ro_next : ro;
+            n_pass -= more;
+            more = n_pass > 1u ? 1u : 0u;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const bool pass = !(sc_(j) < thr_l[qh]);
+            if (pass) {
+              if (off[qh] < end_bytes)
+                out[off[qh] >> 3] = (static_cast<uint64_t>(static_cast<uint32_t>(doc0 + (j & 3) + 16 * (j >> 2))) << 32) |
+                                    __float_as_uint(sc_(j));
+              off[qh] += 8u;   // keeps counting past the end: the finish kernel sees count > capacity
+            }
+          }
+        }
+      }
+#undef sc_
+    }
+  };
+
+  const bool deferred = wave_u >= NW / 2;
+  f32x4a acc[2][2];
+  int64_t prev = -1;
+  int buf = 0;
+  if (first + step < n_tiles) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  for (int64_t i = first; i < n_tiles; i += step) {
+    const bool has_next2 = i + 2 * step < n_tiles;
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const int buf2 = buf + 2 >= kTileBufs ? buf + 2 - kTileBufs : buf + 2;
+
+    constexpr int kAhead = 2;   // fragments in flight ahead of the MFMAs (register budget: 256 with 192 of them queries)
+    u32x4m ring[kAhead + 1];
+    // fragment f = 2 s + dh: address register s & 3, immediate 256 (s >> 2) bytes + 16 rows for dh = 1
+    auto read_fragment = [&](u32x4m& dst, int f) {
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(a_addr[(f >> 1) & 3]), "n"(256 * (f >> 3) + (f & 1) * 16 * UPR * 16));
+    };
+#pragma unroll
+    for (int f = 0; f < kAhead && active; ++f) read_fragment(ring[f], f);
+
+    auto side_phase = [&](bool filter, int64_t filter_tile) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (has_next2) {
+        const __amdgpu_buffer_rsrc_t next_rsrc = tile_rsrc((i + 2 * step) * tile_stride);
+#pragma unroll
+        for (int p = 0; p < PPW; ++p) issue_piece(next_rsrc, buf2, p);
+      }
+      if (filter && active) epilogue(acc, filter_tile);
+    };
+
+    if (deferred) side_phase(prev >= 0, prev);
+    if (active) {
+      if (DEWI_MFMA_PRIO) __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        u32x4m& cur = ring[f % (kAhead + 1)];
+        if (f + kAhead < NF) read_fragment(ring[(f + kAhead) % (kAhead + 1)], f + kAhead);
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(cur) : "n"((NF - 1 - f) < kAhead ? (NF - 1 - f) : kAhead));
+        const bf16x8 a = __builtin_bit_cast(bf16x8, cur);
+        const f32x4a zero = {0.f, 0.f, 0.f, 0.f};
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int s = f >> 1, dh = f & 1;
+        acc[dh][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[0][s], s == 0 ? zero : acc[dh][0], 0, 0, 0);
+        acc[dh][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[1][s], s == 0 ? zero : acc[dh][1], 0, 0, 0);
+      }
+      if (DEWI_MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
+    }
+    if (!deferred) side_phase(true, i);
+    prev = i;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a_addr[j] = buf == kTileBufs - 1 ? a_addr[j] - (kTileBufs - 1) * TILE_BYTES : a_addr[j] + TILE_BYTES;
+    buf = buf == kTileBufs - 1 ? 0 : buf + 1;
+  }
+  if (deferred && prev >= 0 && active) epilogue(acc, prev);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (!DENSE) {
+#pragma unroll
+    for (int qh = 0; qh < 2; ++qh) {
+      const uint32_t seg_q = (static_cast<uint32_t>(blockIdx.x) * 4 + g) * kQueriesPerPass + (32 * wave + 16 * qh + c);
+      cnt[seg_q] = (off[qh] >> 3) - seg_q * static_cast<uint32_t>(out_stride);
+    }
+  } else if (active) {
+#pragma unroll
+    for (int qh = 0; qh < 2; ++qh) {
+      f32x4v* dst = reinterpret_cast<f32x4v*>(reinterpret_cast<float*>(out) +
+                                              static_cast<int64_t>(32 * wave + 16 * qh + c) * out_stride +
+                                              (static_cast<int64_t>(blockIdx.x) * 4 + g) * 8);
+      dst[0] = f32x4v{mx[qh][0], mx[qh][1], mx[qh][2], mx[qh][3]};
+      dst[1] = f32x4v{mx[qh][4], mx[qh][5], mx[qh][6], mx[qh][7]};
+    }
+  }
+#endif
+}
+
 // Per-query threshold from the dense sample scores: the score of the c-th best sample document is a
 // lower bound of the query's final c-th best score.  One workgroup per query; exact 3-pass MSB radix
 // select (11 + 11 + 10 bits) on the order-preserving keys of the n_sample fp32 scores.
@@ -648,7 +949,7 @@ MfmaLayout plan_mfma(int64_t n_rows, int dim, int n_queries, int n_candidates, i
   // Expected survivors per query ~ n_rows * c / n_sample = 32 c, spread evenly over the half-segments;
   // 4x head-room, at least 32 records.
   m.n_blocks = m.n_tiles < compute_units ? static_cast<int>(m.n_tiles) : compute_units;
-  m.n_seg = 2 * m.n_blocks;
+  m.n_seg = kSegPerBlock * m.n_blocks;
   int64_t cap = (4ll * kSampleStride * n_candidates + m.n_seg - 1) / m.n_seg;
   m.seg_cap = static_cast<int>(cap < 32 ? 32 : cap);
   size_t off = 0;
@@ -680,6 +981,14 @@ hipError_t launch_sample_threshold(const float* dense, int64_t n_sample, int64_t
   return hipGetLastError();
 }
 
+using ScanKernel = void (*)(const uint16_t*, int64_t, const uint16_t*, int64_t, int64_t, const float*, uint64_t*, int64_t, uint32_t*,
+                            int);
+template <int KS, bool DENSE>
+static ScanKernel scan_kernel() {
+  if constexpr (kShape16) return &mfma_scan_bf16_s16<KS, DENSE>;
+  return &mfma_scan_bf16<KS, DENSE>;
+}
+
 template <int KS>
 static hipError_t run_mfma_dim(const MfmaLayout& m, const uint16_t* E, int64_t n_rows, int n_queries, int n_candidates,
                                char* ws, int compute_units, hipStream_t stream) {
@@ -687,10 +996,10 @@ static hipError_t run_mfma_dim(const MfmaLayout& m, const uint16_t* E, int64_t n
   const int lds_bytes = kTileBufs * kTileRows * DIM * 2;
   static PerDeviceOnce attr_once;   // one per KS instantiation
   const hipError_t ea = attr_once.run([] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan_bf16<KS, true>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(scan_kernel<KS, true>()),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan_bf16<KS, false>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(scan_kernel<KS, false>()),
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   });
   if (ea != hipSuccess) return ea;
@@ -707,7 +1016,8 @@ static hipError_t run_mfma_dim(const MfmaLayout& m, const uint16_t* E, int64_t n
     const int n_active = n_queries - g * kQueriesPerPass < kQueriesPerPass ? n_queries - g * kQueriesPerPass : kQueriesPerPass;
     // 1. dense scores of the strided sample
     const int sample_blocks = m.n_sample_tiles < compute_units ? static_cast<int>(m.n_sample_tiles) : compute_units;
-    hipLaunchKernelGGL((mfma_scan_bf16<KS, true>), dim3(sample_blocks), dim3(kMfmaThreads), lds_bytes, stream, E, n_rows,
+    const ScanKernel k_sample = scan_kernel<KS, true>(), k_filter = scan_kernel<KS, false>();
+    hipLaunchKernelGGL(k_sample, dim3(sample_blocks), dim3(kMfmaThreads), lds_bytes, stream, E, n_rows,
                        qg, m.n_sample_tiles, static_cast<int64_t>(kSampleStride), static_cast<const float*>(nullptr),
                        reinterpret_cast<uint64_t*>(dense), m.sample_stride, static_cast<uint32_t*>(nullptr), n_active);
     // 2. per-query threshold (real queries only: a padding query's sample scores are all equal, which is the
@@ -717,7 +1027,7 @@ static hipError_t run_mfma_dim(const MfmaLayout& m, const uint16_t* E, int64_t n
     // 3. full pass with the filter: n_blocks workgroups, each writing its own half-segments and counts
     //    (the kernel dewi_timing_read reports: algorithmic bytes = n_rows * dim * 2 per launch)
     timing_begin(stream);
-    hipLaunchKernelGGL((mfma_scan_bf16<KS, false>), dim3(m.n_blocks), dim3(kMfmaThreads), lds_bytes, stream, E, n_rows, qg,
+    hipLaunchKernelGGL(k_filter, dim3(m.n_blocks), dim3(kMfmaThreads), lds_bytes, stream, E, n_rows, qg,
                        m.n_tiles, static_cast<int64_t>(1), static_cast<const float*>(tg), og,
                        static_cast<int64_t>(m.seg_cap), cg, n_active);
     timing_end(stream);

@@ -37,5 +37,5 @@ pmc WRITE_SIZE_c3 WRITE_SIZE --config c3 --steps 10 --warmup 2
 pmc SQ_LDS_c3 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES" --config c3 --steps 10 --warmup 2
 pmc SQ_MFMA_c3 "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_COEXEC_CYCLES" --config c3 --steps 10 --warmup 2
 pmc SQ_WAIT_c3 "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" --config c3 --steps 10 --warmup 2
-python3 scripts/summarize_pmc.py $OUT --commit $COMMIT --record "1000000x768x4xB1=scan_rows_f32" "1000000x768x2xB256=mfma_scan_bf16<48, false>" > $OUT/pmc_summary.txt
+python3 scripts/summarize_pmc.py $OUT --commit $COMMIT --record "1000000x768x4xB1=scan_rows_f32" "1000000x768x2xB256=mfma_scan_bf16_s16<48, false>" > $OUT/pmc_summary.txt
 cat $OUT/pmc_summary.txt
