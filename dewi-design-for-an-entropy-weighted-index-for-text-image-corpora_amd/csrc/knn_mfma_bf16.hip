@@ -120,20 +120,55 @@ __global__ __launch_bounds__(kWave) void prepare_queries_bf16(const float* __res
     return;
   }
   const float* q = Q + static_cast<int64_t>(row) * dim;
+  auto to_bf16 = [](float v) {
+    const uint32_t u = __float_as_uint(v);
+    return (v != v) ? static_cast<uint16_t>((u >> 16) | 0x0040u) : static_cast<uint16_t>((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+  };
+  // dim % 4 == 0 and at most 2048 (every matrix-core path): the row stays in registers — all of its 16-byte loads
+  // are in flight together, one pass for the norm, one for the division, 8-byte stores (the one-element-at-a-time
+  // loops below cost 7-8 us per launch in load round trips for a 768 KB job)
+  if ((dim & 3) == 0 && dim <= 2048) {
+    typedef float f32x4p __attribute__((ext_vector_type(4)));
+    typedef uint16_t u16x4p __attribute__((ext_vector_type(4)));
+    const int n4 = dim >> 2;
+    f32x4p v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = lane + u * kWave;
+      v[u] = j < n4 ? reinterpret_cast<const f32x4p*>(q)[j] : f32x4p{0.f, 0.f, 0.f, 0.f};
+    }
+    float norm = 1.f;
+    bool scale = false;
+    if (space == DEWI_SPACE_COSINE) {
+      double ss = 0.0;   // float64: the same norm as every other kernel's (common.hpp, wave_query_norm)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) ss += square_f64(v[u].x) + square_f64(v[u].y) + square_f64(v[u].z) + square_f64(v[u].w);
+      norm = wave_query_norm(ss);
+      scale = norm > 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = lane + u * kWave;
+      if (j < n4) {
+        u16x4p r;
+        r.x = to_bf16(scale ? __fdiv_rn(v[u].x, norm) : v[u].x);
+        r.y = to_bf16(scale ? __fdiv_rn(v[u].y, norm) : v[u].y);
+        r.z = to_bf16(scale ? __fdiv_rn(v[u].z, norm) : v[u].z);
+        r.w = to_bf16(scale ? __fdiv_rn(v[u].w, norm) : v[u].w);
+        reinterpret_cast<u16x4p*>(o)[j] = r;
+      }
+    }
+    return;
+  }
   float norm = 1.f;
   bool scale = false;
   if (space == DEWI_SPACE_COSINE) {
-    double ss = 0.0;   // float64: the same norm as every other kernel's (common.hpp, wave_query_norm)
+    double ss = 0.0;
     for (int j = lane; j < dim; j += kWave) ss += square_f64(q[j]);
     norm = wave_query_norm(ss);
     scale = norm > 0.f;
   }
-  for (int j = lane; j < dim; j += kWave) {
-    const float v = scale ? __fdiv_rn(q[j], norm) : q[j];
-    const uint32_t u = __float_as_uint(v);
-    o[j] = (v != v) ? static_cast<uint16_t>((u >> 16) | 0x0040u)
-                    : static_cast<uint16_t>((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
-  }
+  for (int j = lane; j < dim; j += kWave) o[j] = to_bf16(scale ? __fdiv_rn(q[j], norm) : q[j]);
 }
 
 // KS = dim / 16 MFMA k-steps (dim % 128 == 0, dim <= 768).

@@ -250,21 +250,60 @@ __global__ __launch_bounds__(kWave) void prepare_queries_f32(const float* __rest
     for (int j = lane; j < dim; j += kWave) o[j] = 0.f;
     return;
   }
+  auto round_bf16 = [](float v) {   // nearest-even bf16, kept as the fp32 value it represents
+    if (v != v) return v;
+    const uint32_t u = __float_as_uint(v);
+    return __uint_as_float((u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u);
+  };
+  // dim % 4 == 0 and at most 2048: the row stays in registers (all loads in flight together, see prepare_queries_bf16)
+  if ((dim & 3) == 0 && dim <= 2048) {
+    const int n4 = dim >> 2;
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = lane + u * kWave;
+      v[u] = j < n4 ? reinterpret_cast<const f32x4*>(q)[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float norm = 1.f;
+    bool scale = false;
+    if (space == DEWI_SPACE_COSINE) {
+      double ss = 0.0;   // float64: the same norm as every other kernel's (common.hpp, wave_query_norm)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) ss += square_f64(v[u].x) + square_f64(v[u].y) + square_f64(v[u].z) + square_f64(v[u].w);
+      norm = wave_query_norm(ss);
+      scale = norm > 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = lane + u * kWave;
+      if (j < n4) {
+        f32x4 r;
+        r.x = scale ? __fdiv_rn(v[u].x, norm) : v[u].x;
+        r.y = scale ? __fdiv_rn(v[u].y, norm) : v[u].y;
+        r.z = scale ? __fdiv_rn(v[u].z, norm) : v[u].z;
+        r.w = scale ? __fdiv_rn(v[u].w, norm) : v[u].w;
+        if (to_bf16) {
+          r.x = round_bf16(r.x);
+          r.y = round_bf16(r.y);
+          r.z = round_bf16(r.z);
+          r.w = round_bf16(r.w);
+        }
+        reinterpret_cast<f32x4*>(o)[j] = r;
+      }
+    }
+    return;
+  }
   float norm = 1.f;
   bool scale = false;
   if (space == DEWI_SPACE_COSINE) {
-    double ss = 0.0;   // float64: the same norm as every other kernel's (common.hpp, wave_query_norm)
+    double ss = 0.0;
     for (int j = lane; j < dim; j += kWave) ss += square_f64(q[j]);
     norm = wave_query_norm(ss);
     scale = norm > 0.f;
   }
   for (int j = lane; j < dim; j += kWave) {
-    float v = scale ? __fdiv_rn(q[j], norm) : q[j];
-    if (to_bf16 && v == v) {  // round to nearest-even bf16, kept as the fp32 value it represents
-      const uint32_t u = __float_as_uint(v);
-      v = __uint_as_float((u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u);
-    }
-    o[j] = v;
+    const float v = scale ? __fdiv_rn(q[j], norm) : q[j];
+    o[j] = to_bf16 ? round_bf16(v) : v;
   }
 }
 
