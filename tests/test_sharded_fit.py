@@ -232,3 +232,39 @@ def test_two_ranks_on_one_gpu_fit_equals_oracle():
             for k in KEYS:
                 assert np.array_equal(np.float64(med[k]), np.float64(med_e[k]), equal_nan=True), (name, r, k)
                 assert (np.isnan(mad_e[k]) and np.isnan(mad[k])) or mad[k] == mad_e[k], (name, r, k)
+
+
+@pytest.mark.gpu
+def test_c5_eight_shards_on_one_gpu_full_size():
+    """Config C5's fit at its full size (1M documents x 7 signals) as EIGHT doc-id shards, replayed in one process
+    on one GPU: every shard runs the real histogram steps on its 125 K rows (its own workspace), the regions the
+    ranks would all-reduce over RCCL are summed here with torch, every shard picks with the global row count.  All
+    eight must arrive at the oracle's medians / MADs bit for bit — and at the single-device two-launch fit's.
+    (The wire itself — RCCL with 8 ranks — is not exercised: multi-GPU is unmeasured on hardware.)"""
+    from dewi.scorer import RobustStats
+    from dewi.sharded import HipFitSteps, shard_bounds
+    n, world = 1_000_000, 8
+    t = _table(n, 55, with_nan=False, ties=True)
+    steps = [HipFitSteps(torch.from_numpy(np.ascontiguousarray(t[:, lo:hi])).cuda()) for lo, hi in shard_bounds(n, world)]
+    for st in steps:
+        st.begin()
+    out = []
+    for phase in (0, 1):
+        for pass_ in (0, 1, 2):
+            for st in steps:
+                st.hist(phase, pass_)
+            regions = [st.regions(phase, pass_) for st in steps]
+            for which in range(len(regions[0])):                    # what dist.all_reduce(SUM) does on 8 ranks
+                total = torch.stack([r[which] for r in regions]).sum(dim=0, dtype=torch.int32)
+                for r in regions:
+                    r[which].copy_(total)
+            for st in steps:
+                st.pick(n, phase, pass_)
+        out.append([st.finish(n, phase).cpu().numpy().copy() for st in steps])
+    med_e, mad_e = _expected(t)
+    whole = RobustStats.fit_columns({k: t[j] for j, k in enumerate(KEYS)})
+    for r in range(world):
+        for j, k in enumerate(KEYS):
+            med, mad = float(np.float64(out[0][r][j])), float(np.float64(out[1][r][j])) or 1e-8
+            assert med == med_e[k] == whole.medians[k], (r, k, med, med_e[k])
+            assert mad == mad_e[k] == whole.mads[k], (r, k, mad, mad_e[k])
