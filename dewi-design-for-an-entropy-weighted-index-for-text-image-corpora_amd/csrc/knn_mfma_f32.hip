@@ -4,24 +4,35 @@
 // Same contract as the scan kernels — steps 1-3 of ExactIndex.search (reference
 // src/dewi/backends.py:420-444) on the reference's native dtype (fp32 rows, backends.py:403) — for
 // query batches: `search_batch` on an fp32 corpus was vector-ALU-bound (8 queries per pass 0.68 ms at
-// 1M x 768); v_mfma_f32_32x32x2_f32 computes a 32-document x 32-query block at the fp32 vector rate
-// with EXACT fp32 products and fp32 accumulation (an fmaf chain, bit for bit), so 32 queries cost one
-// corpus pass.
+// 1M x 768); on the matrix cores 32 queries cost one corpus pass.
 //
-// Roofline: co-limited.  Algorithmic bytes per pass = n_rows * dim * 4 (HBM, the corpus read once);
-// flops = 2 * 32 * n_rows * dim (49 GFLOP at 1M x 768) at the 157 TFLOP/s fp32 matrix peak = 0.31 ms
-// against 0.38 ms at 8 TB/s.
+// ARITHMETIC (DEWI_F32_SPLIT, dims up to 1024).  gfx950 has no fast fp32 matrix instruction:
+// v_mfma_f32_32x32x2_f32 runs at the fp32 vector rate (157 TFLOP/s), and 32 queries x 1M x 768 are
+// 49 GFLOP = 0.31 ms of a saturated matrix pipe beside a 0.38 ms HBM pass — the first version of this
+// kernel sat in that corner (pipe busy 70 %, clock down to 1.7 GHz, pass 0.50-0.53 ms).  Now every fp32
+// value is cut into three bf16 pieces, x = hi + mid + lo EXACTLY (8 + 8 + 8 significand bits), and a
+// block of products is six v_mfma_f32_32x32x16_bf16 (lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi,
+// smallest first) with exact products and fp32 accumulation.  The three dropped terms (mid*lo, lo*mid,
+// lo*lo) are below 2^-23 |q_i e_i| each — one fp32 rounding of that product — so scores stay fp32-grade
+// (tests/test_hip_mfma_f32.py bounds |score - f64| <= 3e-7 on heavy-tailed vectors; NaN stays NaN).
+// Per chunk and wave: 12 matrix instructions of 32 cycles instead of 16 of 64, plus 72 vector
+// instructions for the cut (v_cvt_pk_bf16_f32 / shift / and / v_pk_add_f32): the pass drops to
+// 0.445-0.48 ms (6.4-6.9 TB/s).  Dim 1536 would need 144 registers of query pieces per lane and keeps
+// v_mfma_f32_32x32x2_f32 on the fp32 values (exact products, an fmaf chain per depth slice).
+//
+// Roofline: HBM.  Algorithmic bytes per pass = n_rows * dim * 4 (the corpus read once), 0.38 ms at
+// 8 TB/s for 1M x 768; flops = 6 * 2 * 32 * n_rows * dim bf16 (0.29 PFLOP) = 0.12 ms at 2.5 PFLOP/s.
 //
 // Structure (one 8-wave workgroup per CU, persistent over 32-document tiles):
 //  * A tile is cut into CHUNKS of 32 rows x 256 columns (32 KiB): 32 DMA pieces of 1 KiB = one row's
 //    256 columns each (buffer_load_dwordx4 ... lds, global -> LDS without registers), ring of four
 //    chunks: one being multiplied, three in flight (96 KiB per CU).
 //  * THE EIGHT WAVES SPLIT THE DEPTH: wave w multiplies columns [32w, 32w+32) of every chunk, so its
-//    share of the 32 normalised queries is dim/8 columns = dim/16 registers per lane (48 at dim 768)
-//    and lives in registers for the whole kernel.  Per chunk and wave: 4 ds_read_b128 (lane (r, h)
-//    takes columns 32w + 8m + 4h .. +3 of row r, m = 0..3) and 16 MFMAs — MFMA 4m+i multiplies
-//    column 32w + 8m + 4h + i on both operands (the k index of an MFMA is only a pairing of A and B
-//    lanes, so any column may stand at any k as long as both sides agree).
+//    share of the 32 normalised queries is dim/8 columns (as three bf16 pieces: 72 registers per lane
+//    at dim 768) and lives in registers for the whole kernel.  Per chunk and wave: 4 ds_read_b128 (lane
+//    (r, h) takes columns 32w + 8m + 4h .. +3 of row r, m = 0..3); reads 2p and 2p+1 make the eight
+//    k-slots of lane half h in MFMA group p (the k index of an MFMA is only a pairing of A and B lanes,
+//    so any column may stand at any k as long as both sides agree).
 //  * BANK CONFLICTS: chunk rows are 1 KiB apart, so the 16 lanes of a ds_read_b128 group (16 rows, same
 //    column unit) would all hit the same banks.  The LDS image is linear per piece and the SOURCE
 //    address is permuted: 16-byte unit u of row r is stored at unit u ^ (r & 15); reads apply the same
@@ -32,9 +43,9 @@
 //  * THRESHOLDS AND SURVIVORS as in the bf16 matrix-core path (knn_mfma_bf16.hip): a sample pass of the
 //    same kernel over every `sample_stride`-th tile keeps group maxima, their c-th largest is a valid
 //    lower bound of the query's c-th best score; the full pass stores every score that is not below it
-//    as a raw record (row << 32 | score bits) into the (workgroup, query) segment — the slot comes
-//    from a per-query counter in LDS (survivors are rare here: ~0.1 per tile and workgroup) — and the
-//    select kernel finishes exactly.  A segment that overflows (adversarial corpora) marks the query
+//    as a raw record (row << 32 | score bits) into the (workgroup, query) segment — a survivor waits
+//    in its lane until a second one needs the same place, then the wave's waiting records go out
+//    together, slots from a per-query counter in LDS — and the select kernel finishes exactly.  A segment that overflows (adversarial corpora) marks the query
 //    (count > capacity): ids -1, the caller re-runs it on the exact small-batch kernels.
 #include "select_common.hpp"
 
@@ -69,11 +80,39 @@ constexpr int kF32RedRegs = 15;                                     // LDS slots
 constexpr int kF32RedBytes = kF32Waves * kF32RedRegs * kWave * 4;   // 30 KiB
 template <bool BF16>
 constexpr int depth_lds_bytes() { return DepthGeo<BF16>::kRing * DepthGeo<BF16>::kChunk + kF32RedBytes + kF32Queries * 4; }
+// fp32 corpus arithmetic (see ARITHMETIC above): 1 = three-piece bf16 cut + six bf16 MFMAs, 0 = v_mfma_f32_32x32x2_f32.
+#ifndef DEWI_F32_SPLIT
+#define DEWI_F32_SPLIT 1
+#endif
 #ifndef DEWI_F32MFMA_DMA_AUX
 #define DEWI_F32MFMA_DMA_AUX 2   // non-temporal tile DMA: the corpus is read once
 #endif
 
 using LdsPtrF = void __attribute__((address_space(3)))*;
+
+typedef float f32x2f __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16_rne(f32x2f v) {      // v_cvt_pk_bf16_f32
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2f));
+}
+__device__ __forceinline__ f32x2f widen_bf16(uint32_t pk) {
+  return f32x2f{__builtin_bit_cast(float, pk << 16), __builtin_bit_cast(float, pk & 0xffff0000u)};
+}
+// Eight fp32 values (two 16-byte reads) -> three bf16x8 operands with x = hi + mid + lo exactly: x - hi is exact
+// (hi holds x's leading 8 bits, rounded), at most 16 bits long; mid takes its leading 8, what is left fits the 8
+// bits of lo.  9 vector instructions per pair of values (cvt_pk, shift, and, pk_add; twice; cvt_pk).  NaN stays NaN.
+__device__ __forceinline__ void split3(const u32x4f& x0, const u32x4f& x1, u32x4f& hi, u32x4f& mid, u32x4f& lo) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t ua = j < 2 ? x0[2 * j] : x1[2 * j - 4], ub = j < 2 ? x0[2 * j + 1] : x1[2 * j - 3];
+    const f32x2f x = {__builtin_bit_cast(float, ua), __builtin_bit_cast(float, ub)};
+    hi[j] = pack_bf16_rne(x);
+    const f32x2f r1 = x - widen_bf16(hi[j]);
+    mid[j] = pack_bf16_rne(r1);
+    const f32x2f r2 = r1 - widen_bf16(mid[j]);
+    lo[j] = pack_bf16_rne(r2);
+  }
+}
 
 // CH = dim / 256 chunks per tile.  Tiles of this launch: t = (blockIdx.x + i * gridDim.x) * tile_stride.
 // SAMPLE: out is a float array [32][out_stride]: out[q * out_stride + (16 * blockIdx.x + 2 * wave + h) * 2 + e] =
@@ -100,13 +139,24 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
 
   // ---- this wave's share of the queries (B operand), 16 bytes per read m: lane (r, h) holds
   //      fp32: Qn[r][256 ch + 32 w + 8 m + 4 h .. +3]  (4 MFMAs)     bf16: Qn[r][256 ch + 32 w + 16 m + 8 h .. +7]  (1 MFMA)
-  u32x4f qf[CH][G::kReads];
+  //      split fp32: reads 2p and 2p+1 are cut into qf[ch][3p + 0 / 1 / 2] = hi / mid / lo (8 columns per operand)
+  constexpr bool kSplit = !BF16 && DEWI_F32_SPLIT && CH <= 4;   // dim 1536: three query pieces would not fit the registers
+  constexpr int kQRegs = kSplit ? 6 : G::kReads;
+  u32x4f qf[CH][kQRegs];
 #pragma unroll
   for (int ch = 0; ch < CH; ++ch) {
+    u32x4f raw[G::kReads];
 #pragma unroll
     for (int m = 0; m < G::kReads; ++m) {
       const char* qrow = static_cast<const char*>(Qn) + static_cast<int64_t>(r) * DIM * G::kElem;
-      qf[ch][m] = *reinterpret_cast<const u32x4f*>(qrow + kF32ChunkCols * G::kElem * ch + 32 * G::kElem * w + 16 * (2 * m + h));
+      raw[m] = *reinterpret_cast<const u32x4f*>(qrow + kF32ChunkCols * G::kElem * ch + 32 * G::kElem * w + 16 * (2 * m + h));
+    }
+    if constexpr (kSplit) {
+      split3(raw[0], raw[1], qf[ch][0], qf[ch][1], qf[ch][2]);
+      split3(raw[2], raw[3], qf[ch][3], qf[ch][4], qf[ch][5]);
+    } else {
+#pragma unroll
+      for (int m = 0; m < G::kReads; ++m) qf[ch][m] = raw[m];
     }
   }
   const float thr_l = SAMPLE ? -__builtin_inff() : (r < n_active ? thr[r] : __builtin_inff());
@@ -115,7 +165,7 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
 #pragma unroll
   for (int ch = 0; ch < CH; ++ch) {
 #pragma unroll
-    for (int m = 0; m < G::kReads; ++m) asm volatile("" ::"v"(qf[ch][m]));
+    for (int m = 0; m < kQRegs; ++m) asm volatile("" ::"v"(qf[ch][m]));
   }
   asm volatile("" ::"v"(thr_l));
   if (!SAMPLE && threadIdx.x < kF32Queries) lcnt[threadIdx.x] = 0;   // read first at a tile end, behind several barriers
@@ -218,6 +268,33 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
     }
   };
   float mx0 = -__builtin_inff(), mx1 = -__builtin_inff();
+  // survivors waiting in this lane: raw records (row << 32 | score bits) of query r go to the (workgroup, query)
+  // segment, the slot comes from the query's counter in LDS
+  constexpr uint32_t kNoDoc = 0xffffffffu;
+  uint32_t pend_doc0 = kNoDoc, pend_doc1 = kNoDoc;
+  float pend_s0 = 0.f, pend_s1 = 0.f;
+  auto flush_pending = [&]() {
+    const uint32_t cap = static_cast<uint32_t>(out_stride);
+    uint64_t* seg = out + (static_cast<int64_t>(blockIdx.x) * kF32Queries + r) * out_stride;
+    // Inline asm: for a plain atomicAdd on LDS hipcc first waits for vmcnt(0) — every LDS-DMA piece in flight could
+    // alias the counter as far as it knows — which would drain this wave's ring on every flush.
+    const uint32_t cnt_addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((LdsPtrF)(lcnt))) + 4u * static_cast<uint32_t>(r);
+    auto take_slot = [&]() {
+      uint32_t slot;
+      asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(slot) : "v"(cnt_addr), "v"(1u) : "memory");
+      return slot;
+    };
+    if (pend_doc0 != kNoDoc) {
+      const uint32_t slot = take_slot();
+      if (slot < cap) seg[slot] = (static_cast<uint64_t>(pend_doc0) << 32) | __float_as_uint(pend_s0);
+      pend_doc0 = kNoDoc;
+    }
+    if (pend_doc1 != kNoDoc) {
+      const uint32_t slot = take_slot();
+      if (slot < cap) seg[slot] = (static_cast<uint64_t>(pend_doc1) << 32) | __float_as_uint(pend_s1);
+      pend_doc1 = kNoDoc;
+    }
+  };
   auto stage2_finish = [&](int64_t it) {             // fixed summation order 0..7 whichever wave sums; then the filter
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
@@ -234,27 +311,20 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
       mx0 = __builtin_fmaxf(mx0, s0);
       mx1 = __builtin_fmaxf(mx1, s1);
     } else {
+      // A survivor waits in its lane (one place per accumulator register) until a second one arrives for the same
+      // place somewhere in the wave; then the whole wave's waiting records go out together.  A vector store issued
+      // into the full DMA queue costs the workgroup ~0.1 us at its next barrier whether it carries one record or
+      // sixty-four (a batch of 32 ran 40 us behind a batch of 8 on per-survivor stores; taking the LDS slots
+      // alone cost nothing), and a wave collects ~14 survivors before two meet.
       const bool pass0 = !(s0 < thr_l), pass1 = !(s1 < thr_l);         // NaN passes (NumPy ranks NaN first)
-      if (__builtin_amdgcn_ballot_w64(pass0 || pass1) != 0ull) {
-        const uint32_t cap = static_cast<uint32_t>(out_stride);
-        uint64_t* seg = out + (static_cast<int64_t>(blockIdx.x) * kF32Queries + r) * out_stride;
-        // the slot comes from the query's counter in LDS.  Inline asm: for a plain atomicAdd on LDS hipcc first
-        // waits for vmcnt(0) — every LDS-DMA piece in flight could alias the counter as far as it knows — which
-        // would drain this wave's ring (and stall the workgroup at the next barrier) on every survivor.
-        const uint32_t cnt_addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((LdsPtrF)(lcnt))) + 4u * static_cast<uint32_t>(r);
-        auto take_slot = [&]() {
-          uint32_t slot;
-          asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(slot) : "v"(cnt_addr), "v"(1u) : "memory");
-          return slot;
-        };
-        if (pass0) {
-          const uint32_t slot = take_slot();
-          if (slot < cap) seg[slot] = (static_cast<uint64_t>(static_cast<uint32_t>(doc)) << 32) | __float_as_uint(s0);
-        }
-        if (pass1) {
-          const uint32_t slot = take_slot();
-          if (slot < cap) seg[slot] = (static_cast<uint64_t>(static_cast<uint32_t>(doc + 1)) << 32) | __float_as_uint(s1);
-        }
+      if (__builtin_amdgcn_ballot_w64((pass0 && pend_doc0 != kNoDoc) || (pass1 && pend_doc1 != kNoDoc)) != 0ull) flush_pending();
+      if (pass0) {
+        pend_doc0 = static_cast<uint32_t>(doc);
+        pend_s0 = s0;
+      }
+      if (pass1) {
+        pend_doc1 = static_cast<uint32_t>(doc + 1);
+        pend_s1 = s1;
       }
     }
   };
@@ -293,23 +363,49 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
       if (finish_prev) stage2_load();
       const __amdgpu_buffer_rsrc_t rs4 = tile_rsrc(it + (ch + G::kRing) / CH);
       __builtin_amdgcn_sched_barrier(0);
+      const f32x16f zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if constexpr (kSplit) {
+        // two groups of 8 columns: the cut (36 vector instructions) and six MFMAs each; the DMA pieces go out behind
+        // the third and sixth MFMA of a group
 #pragma unroll
-      for (int m = 0; m < G::kReads; ++m) {
-        const f32x16f zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if constexpr (BF16) {
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8f, cur[m]), __builtin_bit_cast(bf16x8f, qf[ch][m]),
-                                                        (ch == 0 && m == 0) ? zero : acc, 0, 0, 0);
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const uint32_t au = cur[m][i], qu = qf[ch][m][i];    // copy the lane to a scalar before the bit cast
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, au), __builtin_bit_cast(float, qu),
-                                                       (ch == 0 && m == 0 && i == 0) ? zero : acc, 0, 0, 0);
-          }
+        for (int p = 0; p < 2; ++p) {
+          u32x4f ah, am, al;
+          split3(cur[2 * p], cur[2 * p + 1], ah, am, al);
+          auto mm = [&](const u32x4f& a, const u32x4f& b, bool first) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8f, a), __builtin_bit_cast(bf16x8f, b),
+                                                          first ? zero : acc, 0, 0, 0);
+          };
+          mm(al, qf[ch][3 * p + 0], ch == 0 && p == 0);
+          mm(ah, qf[ch][3 * p + 2], false);
+          mm(am, qf[ch][3 * p + 1], false);
+          __builtin_amdgcn_sched_barrier(0);
+          issue_piece(rs4, (ch + G::kRing) % CH, static_cast<int>((g + G::kRing) & RM), 2 * p);
+          __builtin_amdgcn_sched_barrier(0);
+          mm(am, qf[ch][3 * p + 0], false);
+          mm(ah, qf[ch][3 * p + 1], false);
+          mm(ah, qf[ch][3 * p + 0], false);
+          __builtin_amdgcn_sched_barrier(0);
+          issue_piece(rs4, (ch + G::kRing) % CH, static_cast<int>((g + G::kRing) & RM), 2 * p + 1);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        issue_piece(rs4, (ch + G::kRing) % CH, static_cast<int>((g + G::kRing) & RM), m);   // kPieces == kReads
-        __builtin_amdgcn_sched_barrier(0);
+      } else {
+#pragma unroll
+        for (int m = 0; m < G::kReads; ++m) {
+          if constexpr (BF16) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8f, cur[m]), __builtin_bit_cast(bf16x8f, qf[ch][m]),
+                                                          (ch == 0 && m == 0) ? zero : acc, 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const uint32_t au = cur[m][i], qu = qf[ch][m][i];    // copy the lane to a scalar before the bit cast
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, au), __builtin_bit_cast(float, qu),
+                                                         (ch == 0 && m == 0 && i == 0) ? zero : acc, 0, 0, 0);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          issue_piece(rs4, (ch + G::kRing) % CH, static_cast<int>((g + G::kRing) & RM), m);   // kPieces == kReads
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       // chunk g+1's fragments (and the previous tile's partials) are in registers
       reads_done(nxt);
@@ -340,6 +436,7 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
 #pragma unroll
     for (int v = 0; v < kF32Waves; ++v) asm volatile("" : "+v"(part[v][0]), "+v"(part[v][1]));
     stage2_finish(n_my - 1);
+    if constexpr (!SAMPLE) flush_pending();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (SAMPLE) {

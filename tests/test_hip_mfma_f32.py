@@ -1,10 +1,14 @@
 """GPU parity tests of the batched fp32 matrix-core path (csrc/knn_mfma_f32.hip) through the C ABI.
 
 The path is taken for >= 5 queries over an fp32 corpus of >= 64 K rows with dim % 256 == 0 (<= 1536),
-cosine space, at most 256 candidates.  v_mfma_f32_32x32x2_f32 multiplies exactly and accumulates in
-fp32, so the oracle comparison is the plain fp32 one (tests/parity.py: ids exactly wherever the f64
-decision gaps exceed 5e-7, scores to 1e-5).  ``search_device`` is called, so a refused query (-1) would
-be seen, not repaired.
+cosine space, at most 256 candidates.  Up to dim 1024 every fp32 value is cut into three bf16 pieces
+(x = hi + mid + lo exactly) and a block of products is six bf16 matrix instructions with exact products
+and fp32 accumulation; the three dropped cross terms are below 2^-23 of |q_i e_i| each, the size of one
+fp32 rounding (dim 1536 keeps v_mfma_f32_32x32x2_f32 on the fp32 values).  So the oracle comparison is
+the plain fp32 one (tests/parity.py: ids exactly wherever the f64 decision gaps exceed 5e-7, scores to
+1e-5), and ``test_mfma_f32_heavy_tailed_components`` bounds the score error itself on vectors whose
+components span six orders of magnitude.  ``search_device`` is called, so a refused query (-1) would be
+seen, not repaired.
 """
 import numpy as np
 import pytest
@@ -48,6 +52,31 @@ def test_mfma_f32_batched_vs_oracle(dim, n, b, k):
         eng.tuning(0, 0, -1, 1)
     assert np.mean(ids_s == ids[:8]) > 0.98
     assert np.allclose(np.sort(sc_s, axis=1), np.sort(sc[:8], axis=1), rtol=0, atol=2e-6)
+
+
+def test_mfma_f32_heavy_tailed_components():
+    """Components spanning six orders of magnitude, a few of them carrying the norm: the three-piece cut of the
+    fp32 values must still give fp32-grade scores (|score - f64 cosine| <= 3e-7, the error of a plain fp32 chain
+    at this depth), not bf16-grade ones (4e-3) or two-piece ones (1.5e-5)."""
+    import torch
+    from dewi import _engine as eng
+    n, dim, b, k = 70_000, 768, 32, 10
+    rng = np.random.default_rng(5)
+    raw = (rng.standard_normal((n, dim)) * np.exp(3.0 * rng.standard_normal((n, dim)))).astype(np.float32)
+    Q = (rng.standard_normal((b, dim)) * np.exp(3.0 * rng.standard_normal((b, dim)))).astype(np.float32)
+    Q[:8] = raw[1000:1008] * (1.0 + 1e-3 * rng.standard_normal((8, dim)).astype(np.float32))   # near-duplicates: cosines near 1
+    cols = orc.synth_payload_columns(n, seed=5)
+    c = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    E = c.emb.cpu().numpy()
+    dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    ids_d, sc_d = c.search_device(torch.from_numpy(Q).cuda(), k, 0.0, 0.0)
+    ids, sc = ids_d.cpu().numpy(), sc_d.cpu().numpy()
+    assert ids.min() >= 0
+    assert [int(ids[j, 0]) for j in range(8)] == list(range(1000, 1008))
+    qn = Q.astype(np.float64) / np.linalg.norm(Q.astype(np.float64), axis=1, keepdims=True)
+    exact = np.einsum("bkd,bd->bk", E[ids].astype(np.float64), qn)
+    assert np.max(np.abs(exact - sc)) <= 3e-7, np.max(np.abs(exact - sc))
+    check_batch(E, Q, dewi32, ent32, k, 0.0, 0.0, "cosine", ids, sc, min_decisive_frac=0.5, exact_gaps=False)
 
 
 def test_mfma_f32_a_batch_of_four_stays_on_the_scan_kernels_and_agrees():
