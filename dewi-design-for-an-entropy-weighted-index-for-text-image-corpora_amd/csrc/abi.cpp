@@ -195,6 +195,102 @@ int check_common(const void* d_E, int64_t n_rows, int dim, const float* d_Q, int
   return DEWI_OK;
 }
 
+// ---- one query batch = a SCAN step (steps 1-3 of ExactIndex.search for every query, into the workspace) and a
+// SELECT step (the exact top-c cut, then either the re-rank or the shard's candidate records).  Three scan paths,
+// chosen from the shapes alone so that dewi_knn_scan and dewi_knn_finish (two calls, two streams) agree:
+//   Rows  : row-per-wave kernels, 1 / 4 / 8 queries per corpus pass (any shape, any space)
+//   Depth : depth-split matrix-core pass, 32 queries per corpus pass (fp32 corpus from 5 queries; bf16 corpus for
+//           2..32 queries, and for larger batches where the 256-query kernel cannot hold the dimension)
+//   Big   : 256-query matrix-core kernel (bf16 corpus, dim <= 768, more than 32 queries)
+enum class BatchPath { Rows, Depth, Big };
+struct BatchPlan {
+  BatchPath path;
+  int c_local;                 // candidates a shard of n_rows can contribute: min(n_candidates, n_rows)
+  KnnLayout rows;
+  dewi::MfmaF32Layout depth;
+  dewi::MfmaLayout big;
+  size_t total;                // workspace bytes of the chosen path
+};
+
+BatchPlan plan_batch(int elem_type, int64_t n_rows, int dim, int n_queries, int n_candidates, int space, int cus) {
+  BatchPlan P{};
+  P.c_local = n_candidates < n_rows ? n_candidates : static_cast<int>(n_rows);
+  // the matrix-core paths select exactly n_candidates rows: a shard with fewer rows stays on the row kernels (padding)
+  const bool mfma = g_tuning.mfma != 0 && P.c_local == n_candidates;
+  const bool depth_ok = mfma && dewi::mfma_f32_path_supported(elem_type, n_rows, dim, n_queries, n_candidates, space);
+  const bool big_ok = mfma && elem_type == 1 && dewi::mfma_path_supported(n_rows, dim, n_queries, n_candidates, space);
+  if (depth_ok && (elem_type == 0 || n_queries <= 32 || !big_ok)) {
+    P.path = BatchPath::Depth;
+    P.depth = dewi::plan_mfma_f32(elem_type, n_rows, dim, n_queries, n_candidates, cus);
+    P.total = P.depth.total;
+  } else if (big_ok) {
+    P.path = BatchPath::Big;
+    P.big = dewi::plan_mfma(n_rows, dim, n_queries, n_candidates, cus);
+    P.total = P.big.total;
+  } else {
+    P.path = BatchPath::Rows;
+    P.rows = layout_knn(n_rows, dim, elem_type ? 2 : 4, n_queries, P.c_local, cus);
+    P.total = P.rows.total;
+  }
+  return P;
+}
+
+int batch_scan(const BatchPlan& P, const void* d_E, int elem_type, int64_t n_rows, int dim, const float* d_Q, int n_queries,
+               int n_candidates, int space, void* d_ws, size_t ws_bytes, int cus, hipStream_t stream) {
+  if (!d_ws || ws_bytes < P.total) return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, P.total);
+  char* ws = static_cast<char*>(d_ws);
+  hipError_t e;
+  switch (P.path) {
+    case BatchPath::Depth:
+      e = dewi::launch_mfma_f32(P.depth, elem_type, d_E, n_rows, dim, d_Q, n_queries, n_candidates, space, ws, stream);
+      return e == hipSuccess ? DEWI_OK : hip_fail(e, "depth-split mfma scan launch");
+    case BatchPath::Big:   // the launcher brackets its filter pass for dewi_timing_read itself
+      e = dewi::launch_mfma_bf16(P.big, static_cast<const uint16_t*>(d_E), n_rows, dim, d_Q, n_queries, n_candidates, space, ws,
+                                 cus, stream);
+      return e == hipSuccess ? DEWI_OK : hip_fail(e, "mfma scan launch");
+    default:
+      return run_scan(P.rows, d_E, elem_type, n_rows, dim, d_Q, n_queries, P.c_local, space, ws, stream);
+  }
+}
+
+// k > 0: ids / scores of the re-ranked top k.  k == 0: n_candidates records per query into d_out_cand (an overflowed
+// query of a matrix-core path carries id -2 there, -1 in the id output).
+int batch_select(const BatchPlan& P, const void* d_ws, size_t ws_bytes, int n_queries, int n_candidates, int k,
+                 const dewi::RerankParams& rp, const float* d_dewi32, const float* d_ent32, int64_t id_offset,
+                 int64_t* d_out_ids, float* d_out_scores, dewi_candidate* d_out_cand, hipStream_t stream) {
+  if (!d_ws || ws_bytes < P.total) return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, P.total);
+  const char* ws = static_cast<const char*>(d_ws);
+  hipError_t e = hipSuccess;
+  if (P.path == BatchPath::Rows) {
+    const KnnLayout& L = P.rows;
+    const int sorted = (L.plan.slots == 1 && P.c_local == n_candidates) ? L.plan.n_lists : 0;
+    e = dewi::launch_select_rerank(reinterpret_cast<const uint64_t*>(ws + L.keys_off), L.plan.keys_per_query, sorted, n_queries,
+                                   n_candidates, k, rp, d_dewi32, d_ent32, id_offset, d_out_ids, d_out_scores, d_out_cand,
+                                   nullptr, dewi::SegmentLayout{}, stream);
+    return e == hipSuccess ? DEWI_OK : hip_fail(e, "select launch");
+  }
+  // matrix-core paths: one select launch per query group (each group has its own survivor segments); up to 8192
+  // survivors of a query (64 KiB) are staged in LDS
+  const bool big = P.path == BatchPath::Big;
+  const int per = big ? 256 : 32;
+  const int groups = big ? P.big.groups : P.depth.groups;
+  const int n_seg = big ? P.big.n_seg : P.depth.n_seg;
+  const int seg_cap = big ? P.big.seg_cap : P.depth.seg_cap;
+  const size_t cand_off = big ? P.big.cand_off : P.depth.cand_off, cnt_off = big ? P.big.cnt_off : P.depth.cnt_off;
+  const dewi::SegmentLayout seg{n_seg, seg_cap, 1, static_cast<int64_t>(per) * seg_cap, per, 8192};
+  for (int g = 0; g < groups && e == hipSuccess; ++g) {
+    const int q0 = g * per;
+    const int nq = n_queries - q0 < per ? n_queries - q0 : per;
+    const uint64_t* keys = reinterpret_cast<const uint64_t*>(ws + cand_off) + static_cast<int64_t>(g) * n_seg * per * seg_cap;
+    const uint32_t* counts = reinterpret_cast<const uint32_t*>(ws + cnt_off) + static_cast<int64_t>(g) * n_seg * per;
+    e = dewi::launch_select_rerank(keys, 0, 0, nq, n_candidates, k, rp, d_dewi32, d_ent32, id_offset,
+                                   d_out_ids ? d_out_ids + static_cast<int64_t>(q0) * k : nullptr,
+                                   d_out_scores ? d_out_scores + static_cast<int64_t>(q0) * k : nullptr,
+                                   d_out_cand ? d_out_cand + static_cast<int64_t>(q0) * n_candidates : nullptr, counts, seg, stream);
+  }
+  return e == hipSuccess ? DEWI_OK : hip_fail(e, "select launch");
+}
+
 // n_candidates_override <= 0: the reference's cut, min(2k, n_rows) (backends.py:439).
 int knn_rerank_impl(const void* d_E, int elem_type, int64_t n_rows, int dim, const float* d_Q, int n_queries,
                     const float* d_dewi32, const float* d_ent32, int k, double eta, double pref, int space,
@@ -219,63 +315,13 @@ int knn_rerank_impl(const void* d_E, int elem_type, int64_t n_rows, int dim, con
   DeviceInfo dev;
   rc = ensure_device(dev);
   if (rc) return rc;
-  char* ws = static_cast<char*>(d_ws);
-  // Which batched path?  fp32 corpus: the depth-split matrix-core pass (32 queries per pass).  bf16 corpus: up to 32
-  // queries -> the depth-split pass (tile-delivery rate); more -> the 256-query kernel where it holds the dimension
-  // in registers (dim <= 768), else depth-split passes of 32.
-  const bool depth_ok = g_tuning.mfma != 0 && dewi::mfma_f32_path_supported(elem_type, n_rows, dim, n_queries, c, space);
-  const bool big_ok = elem_type == 1 && g_tuning.mfma != 0 && dewi::mfma_path_supported(n_rows, dim, n_queries, c, space);
-  const bool use_depth = depth_ok && (elem_type == 0 || n_queries <= 32 || !big_ok);
-  if (big_ok && !use_depth) {
-    // many queries over a bf16 corpus: matrix-core path, one corpus pass per 256 queries
-    const dewi::MfmaLayout M = dewi::plan_mfma(n_rows, dim, n_queries, c, dev.cus);
-    if (!d_ws || ws_bytes < M.total) return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, M.total);
-    hipError_t e = dewi::launch_mfma_bf16(M, static_cast<const uint16_t*>(d_E), n_rows, dim, d_Q, n_queries, c, space, ws,
-                                          dev.cus, stream);   // brackets its filter pass for dewi_timing_read itself
-    if (e != hipSuccess) return hip_fail(e, "mfma scan launch");
-    // one select launch per group of 256 queries (each group has its own segments)
-    const dewi::RerankParams rp = make_rerank(eta, pref, transform, space);
-    for (int g = 0; g < M.groups; ++g) {
-      const int q0 = g * 256;
-      const int nq = n_queries - q0 < 256 ? n_queries - q0 : 256;
-      // expected survivors per query: 32 c; stage up to 8192 of them (64 KiB) in LDS
-      const dewi::SegmentLayout seg{M.n_seg, M.seg_cap, 1, static_cast<int64_t>(256) * M.seg_cap, 256, 8192};
-      const uint64_t* keys = reinterpret_cast<const uint64_t*>(ws + M.cand_off) +
-                             static_cast<int64_t>(g) * M.n_seg * 256 * M.seg_cap;
-      const uint32_t* counts = reinterpret_cast<const uint32_t*>(ws + M.cnt_off) + static_cast<int64_t>(g) * M.n_seg * 256;
-      e = dewi::launch_select_rerank(keys, 0, 0, nq, c, k, rp, d_dewi32, d_ent32, 0, d_out_ids + static_cast<int64_t>(q0) * k,
-                                     d_out_scores + static_cast<int64_t>(q0) * k, nullptr, counts, seg, stream);
-      if (e != hipSuccess) break;
-    }
-    if (e != hipSuccess) return hip_fail(e, "select_rerank launch");
-    return DEWI_OK;
-  }
-  if (use_depth) {
-    // depth-split matrix-core path, one corpus pass per 32 queries
-    const dewi::MfmaF32Layout M = dewi::plan_mfma_f32(elem_type, n_rows, dim, n_queries, c, dev.cus);
-    if (!d_ws || ws_bytes < M.total) return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, M.total);
-    hipError_t e = dewi::launch_mfma_f32(M, elem_type, d_E, n_rows, dim, d_Q, n_queries, c, space, ws, stream);
-    if (e != hipSuccess) return hip_fail(e, "fp32 mfma scan launch");
-    const dewi::RerankParams rp = make_rerank(eta, pref, transform, space);
-    for (int g = 0; g < M.groups; ++g) {
-      const int q0 = g * 32;
-      const int nq = n_queries - q0 < 32 ? n_queries - q0 : 32;
-      const dewi::SegmentLayout seg{M.n_seg, M.seg_cap, 1, static_cast<int64_t>(32) * M.seg_cap, 32, 8192};
-      const uint64_t* keys = reinterpret_cast<const uint64_t*>(ws + M.cand_off) + static_cast<int64_t>(g) * M.n_seg * 32 * M.seg_cap;
-      const uint32_t* counts = reinterpret_cast<const uint32_t*>(ws + M.cnt_off) + static_cast<int64_t>(g) * M.n_seg * 32;
-      e = dewi::launch_select_rerank(keys, 0, 0, nq, c, k, rp, d_dewi32, d_ent32, 0, d_out_ids + static_cast<int64_t>(q0) * k,
-                                     d_out_scores + static_cast<int64_t>(q0) * k, nullptr, counts, seg, stream);
-      if (e != hipSuccess) break;
-    }
-    if (e != hipSuccess) return hip_fail(e, "select_rerank launch");
-    return DEWI_OK;
-  }
-  const KnnLayout L = layout_knn(n_rows, dim, elem_type ? 2 : 4, n_queries, c, dev.cus);
-  if (!d_ws || ws_bytes < L.total) return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, L.total);
-  rc = run_scan(L, d_E, elem_type, n_rows, dim, d_Q, n_queries, c, space, ws, stream);
+  const BatchPlan P = plan_batch(elem_type, n_rows, dim, n_queries, c, space, dev.cus);
+  rc = batch_scan(P, d_E, elem_type, n_rows, dim, d_Q, n_queries, c, space, d_ws, ws_bytes, dev.cus, stream);
   if (rc) return rc;
   const dewi::RerankParams rp = make_rerank(eta, pref, transform, space);
-  if (c > dewi::kMaxSortCandidates) {  // k > 1024: candidate arrays live in global memory
+  if (c > dewi::kMaxSortCandidates) {  // k > 1024 (row kernels only): candidate arrays live in global memory
+    const KnnLayout& L = P.rows;
+    char* ws = static_cast<char*>(d_ws);
     uint64_t* g1 = reinterpret_cast<uint64_t*>(ws + L.big_off);
     hipError_t e2 = dewi::launch_select_rerank_large(reinterpret_cast<const uint64_t*>(ws + L.keys_off),
                                                      L.plan.keys_per_query, n_queries, c, L.p2, k, rp, d_dewi32, d_ent32, g1,
@@ -284,11 +330,7 @@ int knn_rerank_impl(const void* d_E, int elem_type, int64_t n_rows, int dim, con
     if (e2 != hipSuccess) return hip_fail(e2, "select_rerank_large launch");
     return DEWI_OK;
   }
-  hipError_t e = dewi::launch_select_rerank(reinterpret_cast<const uint64_t*>(ws + L.keys_off), L.plan.keys_per_query,
-                                            L.plan.slots == 1 ? L.plan.n_lists : 0, n_queries, c, k, rp, d_dewi32, d_ent32, 0, d_out_ids, d_out_scores, nullptr,
-                                            nullptr, dewi::SegmentLayout{}, stream);
-  if (e != hipSuccess) return hip_fail(e, "select_rerank launch");
-  return DEWI_OK;
+  return batch_select(P, d_ws, ws_bytes, n_queries, c, k, rp, d_dewi32, d_ent32, 0, d_out_ids, d_out_scores, nullptr, stream);
 }
 
 }  // namespace
@@ -399,19 +441,17 @@ int dewi_knn_scan(const void* d_E, int elem_type, int64_t n_rows, int dim, const
   DeviceInfo dev;
   rc = ensure_device(dev);
   if (rc) return rc;
-  const int c_local = n_candidates < n_rows ? n_candidates : static_cast<int>(n_rows);
-  const KnnLayout L = layout_knn(n_rows, dim, elem_type ? 2 : 4, n_queries, c_local, dev.cus);
-  if (!d_workspace || workspace_bytes < L.total)
-    return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, L.total);
-  return run_scan(L, d_E, elem_type, n_rows, dim, d_Q, n_queries, c_local, space, static_cast<char*>(d_workspace),
-                  static_cast<hipStream_t>(stream_));
+  const BatchPlan P = plan_batch(elem_type, n_rows, dim, n_queries, n_candidates, space, dev.cus);
+  return batch_scan(P, d_E, elem_type, n_rows, dim, d_Q, n_queries, n_candidates, space, d_workspace, workspace_bytes, dev.cus,
+                    static_cast<hipStream_t>(stream_));
 }
 
 int dewi_knn_finish(const void* d_workspace, size_t workspace_bytes, int elem_type, int64_t n_rows, int dim,
-                    int n_queries, int n_candidates, int k, double eta, double entropy_pref, const float* d_dewi32,
-                    const float* d_ent32, int64_t id_offset, int64_t* d_out_ids, float* d_out_scores,
-                    dewi_candidate* d_out_cand, void* stream_) {
+                    int n_queries, int n_candidates, int space, int k, double eta, double entropy_pref,
+                    const float* d_dewi32, const float* d_ent32, int64_t id_offset, int64_t* d_out_ids,
+                    float* d_out_scores, dewi_candidate* d_out_cand, void* stream_) {
   if (n_rows <= 0 || dim <= 0 || n_queries <= 0) return fail(DEWI_ERR_INVALID_ARG, "non-positive size");
+  if (space != DEWI_SPACE_COSINE && space != DEWI_SPACE_L2) return fail(DEWI_ERR_INVALID_ARG, "unknown space %d", space);
   if (n_candidates <= 0) return DEWI_OK;
   if (n_candidates > dewi::kMaxSortCandidates)
     return fail(DEWI_ERR_UNSUPPORTED, "n_candidates %d exceeds %d", n_candidates, dewi::kMaxSortCandidates);
@@ -427,18 +467,12 @@ int dewi_knn_finish(const void* d_workspace, size_t workspace_bytes, int elem_ty
   DeviceInfo dev;
   int rc = ensure_device(dev);
   if (rc) return rc;
-  const int c_local = n_candidates < n_rows ? n_candidates : static_cast<int>(n_rows);
-  const KnnLayout L = layout_knn(n_rows, dim, elem_type ? 2 : 4, n_queries, c_local, dev.cus);
-  if (!d_workspace || workspace_bytes < L.total)
-    return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, L.total);
-  const char* ws = static_cast<const char*>(d_workspace);
-  const int sorted = (L.plan.slots == 1 && c_local == n_candidates) ? L.plan.n_lists : 0;
-  hipError_t e = dewi::launch_select_rerank(reinterpret_cast<const uint64_t*>(ws + L.keys_off), L.plan.keys_per_query,
-                                            sorted, n_queries, n_candidates, records ? 0 : k,
-                                            make_rerank(records ? 0.0 : eta, records ? 0.0 : entropy_pref), d_dewi32,
-                                            d_ent32, id_offset, d_out_ids, d_out_scores, d_out_cand, nullptr,
-                                            dewi::SegmentLayout{}, static_cast<hipStream_t>(stream_));
-  return e == hipSuccess ? DEWI_OK : hip_fail(e, "select launch");
+  // the same plan as dewi_knn_scan made (same shapes, same thread's tuning)
+  const BatchPlan P = plan_batch(elem_type, n_rows, dim, n_queries, n_candidates, space, dev.cus);
+  return batch_select(P, d_workspace, workspace_bytes, n_queries, n_candidates, records ? 0 : k,
+                      make_rerank(records ? 0.0 : eta, records ? 0.0 : entropy_pref, DEWI_SIM_RAW, space), d_dewi32, d_ent32,
+                      id_offset, records ? nullptr : d_out_ids, records ? nullptr : d_out_scores, d_out_cand,
+                      static_cast<hipStream_t>(stream_));
 }
 
 int dewi_knn_rerank_bf16(const uint16_t* d_E, int64_t n_rows, int dim, const float* d_Q, int n_queries,
@@ -465,74 +499,13 @@ int dewi_knn_candidates(const void* d_E, int elem_type, int64_t n_rows, int dim,
   DeviceInfo dev;
   rc = ensure_device(dev);
   if (rc) return rc;
-  // a shard can contribute at most n_rows candidates; the rest of each list is padding
-  const int c_local = n_candidates < n_rows ? n_candidates : static_cast<int>(n_rows);
-  const bool depth_ok = g_tuning.mfma != 0 && c_local == n_candidates &&
-                        dewi::mfma_f32_path_supported(elem_type, n_rows, dim, n_queries, n_candidates, space);
-  const bool big_ok = elem_type == 1 && g_tuning.mfma != 0 && c_local == n_candidates &&
-                      dewi::mfma_path_supported(n_rows, dim, n_queries, n_candidates, space);
-  const bool use_depth = depth_ok && (elem_type == 0 || n_queries <= 32 || !big_ok);
-  if (big_ok && !use_depth) {
-    // many queries over a bf16 shard: matrix-core path; an overflowed query's records carry id -2
-    const dewi::MfmaLayout M = dewi::plan_mfma(n_rows, dim, n_queries, n_candidates, dev.cus);
-    if (!d_workspace || workspace_bytes < M.total)
-      return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, M.total);
-    char* wsm = static_cast<char*>(d_workspace);
-    hipError_t e = dewi::launch_mfma_bf16(M, static_cast<const uint16_t*>(d_E), n_rows, dim, d_Q, n_queries, n_candidates,
-                                          space, wsm, dev.cus, stream);
-    if (e != hipSuccess) return hip_fail(e, "mfma scan launch");
-    const dewi::RerankParams rp0 = make_rerank(0.0, 0.0);
-    for (int g = 0; g < M.groups; ++g) {
-      const int q0 = g * 256;
-      const int nq = n_queries - q0 < 256 ? n_queries - q0 : 256;
-      const dewi::SegmentLayout seg{M.n_seg, M.seg_cap, 1, static_cast<int64_t>(256) * M.seg_cap, 256, 8192};
-      const uint64_t* keys = reinterpret_cast<const uint64_t*>(wsm + M.cand_off) +
-                             static_cast<int64_t>(g) * M.n_seg * 256 * M.seg_cap;
-      const uint32_t* counts = reinterpret_cast<const uint32_t*>(wsm + M.cnt_off) + static_cast<int64_t>(g) * M.n_seg * 256;
-      e = dewi::launch_select_rerank(keys, 0, 0, nq, n_candidates, 0, rp0, d_dewi32, d_ent32, id_offset, nullptr, nullptr,
-                                     d_out + static_cast<int64_t>(q0) * n_candidates, counts, seg, stream);
-      if (e != hipSuccess) break;
-    }
-    if (e != hipSuccess) return hip_fail(e, "select (candidates) launch");
-    return DEWI_OK;
-  }
-  if (use_depth) {
-    // depth-split matrix-core path over a shard; an overflowed query's records carry id -2
-    const dewi::MfmaF32Layout M = dewi::plan_mfma_f32(elem_type, n_rows, dim, n_queries, n_candidates, dev.cus);
-    if (!d_workspace || workspace_bytes < M.total)
-      return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, M.total);
-    char* wsm = static_cast<char*>(d_workspace);
-    hipError_t e = dewi::launch_mfma_f32(M, elem_type, d_E, n_rows, dim, d_Q, n_queries, n_candidates, space, wsm, stream);
-    if (e != hipSuccess) return hip_fail(e, "fp32 mfma scan launch");
-    const dewi::RerankParams rp0 = make_rerank(0.0, 0.0);
-    for (int g = 0; g < M.groups; ++g) {
-      const int q0 = g * 32;
-      const int nq = n_queries - q0 < 32 ? n_queries - q0 : 32;
-      const dewi::SegmentLayout seg{M.n_seg, M.seg_cap, 1, static_cast<int64_t>(32) * M.seg_cap, 32, 8192};
-      const uint64_t* keys = reinterpret_cast<const uint64_t*>(wsm + M.cand_off) + static_cast<int64_t>(g) * M.n_seg * 32 * M.seg_cap;
-      const uint32_t* counts = reinterpret_cast<const uint32_t*>(wsm + M.cnt_off) + static_cast<int64_t>(g) * M.n_seg * 32;
-      e = dewi::launch_select_rerank(keys, 0, 0, nq, n_candidates, 0, rp0, d_dewi32, d_ent32, id_offset, nullptr, nullptr,
-                                     d_out + static_cast<int64_t>(q0) * n_candidates, counts, seg, stream);
-      if (e != hipSuccess) break;
-    }
-    if (e != hipSuccess) return hip_fail(e, "select (candidates) launch");
-    return DEWI_OK;
-  }
-  const KnnLayout L = layout_knn(n_rows, dim, elem_type ? 2 : 4, n_queries, c_local, dev.cus);
-  if (!d_workspace || workspace_bytes < L.total)
-    return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, L.total);
-  char* ws = static_cast<char*>(d_workspace);
-  rc = run_scan(L, d_E, elem_type, n_rows, dim, d_Q, n_queries, c_local, space, ws, stream);
+  // The select step writes n_candidates records per query; a shard with fewer rows than that selects every row and
+  // pads the tail (id = -1, sim = -inf).
+  const BatchPlan P = plan_batch(elem_type, n_rows, dim, n_queries, n_candidates, space, dev.cus);
+  rc = batch_scan(P, d_E, elem_type, n_rows, dim, d_Q, n_queries, n_candidates, space, d_workspace, workspace_bytes, dev.cus, stream);
   if (rc) return rc;
-  dewi::RerankParams rp = make_rerank(0.0, 0.0);
-  // The select kernel writes n_candidates records per query; when the shard has fewer rows than
-  // that, it selects every row and pads the tail (id = -1, sim = -inf).
-  hipError_t e = dewi::launch_select_rerank(reinterpret_cast<const uint64_t*>(ws + L.keys_off), L.plan.keys_per_query,
-                                            (L.plan.slots == 1 && c_local == n_candidates) ? L.plan.n_lists : 0,
-                                            n_queries, n_candidates, 0, rp, d_dewi32, d_ent32, id_offset, nullptr,
-                                            nullptr, d_out, nullptr, dewi::SegmentLayout{}, stream);
-  if (e != hipSuccess) return hip_fail(e, "select (candidates) launch");
-  return DEWI_OK;
+  return batch_select(P, d_workspace, workspace_bytes, n_queries, n_candidates, 0, make_rerank(0.0, 0.0), d_dewi32, d_ent32,
+                      id_offset, nullptr, nullptr, d_out, stream);
 }
 
 int dewi_merge_rerank(const dewi_candidate* d_lists, int n_lists, int n_queries, int list_len, int n_candidates, int k,

@@ -271,18 +271,21 @@ class DeviceCorpus:
 
 
 class PipelinedSearcher:
-    """Two queries in flight on one GPU (throughput mode).
+    """Two query batches in flight on one GPU (throughput mode).
 
-    Query i's scan runs on ``scan_stream``; its finish (select, blend, top-k — or, for a doc-id
+    Batch i's scan runs on ``scan_stream``; its finish (select, blend, top-k — or, for a doc-id
     shard, the candidate records) runs on ``finish_stream`` from one of two workspaces, so it
-    overlaps the scan of query i+1.  Scans themselves stay back to back on one stream: nothing
-    competes with the corpus stream for HBM.  ``submit`` only enqueues; call ``drain`` (or
-    synchronise the finish stream) before reading the outputs.
+    overlaps the scan of batch i+1.  Scans themselves stay back to back on one stream: nothing
+    competes with the corpus stream for HBM.  ``submit`` only enqueues; call ``drain`` before
+    reading the outputs.
 
-    ``dewi_knn_scan`` / ``dewi_knn_finish`` always run the exact scan kernels (never a batched
-    matrix-core pass), so a pipelined answer is never a "refused" (-1) row: there is nothing to
-    repair after ``drain``.  The workspace size is fixed at construction from the constructing
-    thread's tuning (``_engine.tuning`` is thread-local): submit from that thread.
+    ``dewi_knn_scan`` / ``dewi_knn_finish`` take the same kernels as the one-call search (a batch of
+    queries: the matrix-core passes), so a query of a batch can come back refused (id -1, survivor
+    buffer overflowed: adversarial corpora only).  ``drain`` looks at the id output of the last
+    submission into each output buffer and answers such queries again one at a time, in place;
+    candidate records (``out_records``) keep their -2 markers for the merge, as
+    ``DeviceCorpus.candidates_device``.  The workspace size and the path are fixed from the
+    submitting thread's tuning (``_engine.tuning`` is thread-local): construct and submit from one thread.
     """
 
     def __init__(self, corpus: DeviceCorpus, k: int, eta: float, entropy_pref: float, n_queries: int = 1,
@@ -309,6 +312,8 @@ class PipelinedSearcher:
             self._scan_done = [torch.cuda.Event() for _ in range(self.depth)]
             self._finish_done = [torch.cuda.Event() for _ in range(self.depth)]
         self._i = 0
+        self._explicit_c = n_candidates is not None
+        self._written = {}            # id-output buffer -> (queries, ids, scores) of the last batch written there
         self._elem = 1 if corpus.is_bf16 else 0
         self._space = nat.SPACE_CODES[corpus.space]
         self._emb, self._dewi, self._ent = nat.ptr(corpus.emb), nat.ptr(corpus.dewi32), nat.ptr(corpus.ent32)
@@ -334,11 +339,13 @@ class PipelinedSearcher:
         self.finish_stream.wait_event(self._scan_done[slot])
         if out_records is None:
             rc = self._lib.dewi_knn_finish(self._ws[slot].data_ptr(), self._need, self._elem, c.n_rows, c.dim, self.b, self.c,
-                                           self.k, self.eta, self.pref, self._dewi, self._ent, c.id_offset,
+                                           self._space, self.k, self.eta, self.pref, self._dewi, self._ent, c.id_offset,
                                            out_ids.data_ptr(), out_scores.data_ptr(), 0, self._s_fin)
+            if self.b >= 2:
+                self._written[out_ids.data_ptr()] = (q_dev, out_ids, out_scores)
         else:
             rc = self._lib.dewi_knn_finish(self._ws[slot].data_ptr(), self._need, self._elem, c.n_rows, c.dim, self.b, self.c,
-                                           0, 0.0, 0.0, self._dewi, self._ent, c.id_offset, 0, 0,
+                                           self._space, 0, 0.0, 0.0, self._dewi, self._ent, c.id_offset, 0, 0,
                                            out_records.data_ptr(), self._s_fin)
         if rc:
             nat.check(rc)
@@ -348,6 +355,19 @@ class PipelinedSearcher:
         for st in self._scan_streams:
             st.synchronize()
         self.finish_stream.synchronize()
+        if not self._written:
+            return
+        torch = _torch()
+        written, self._written = self._written, {}
+        with torch.cuda.device(self.corpus.device):
+            for q_dev, out_ids, out_scores in written.values():
+                if out_ids.numel() == 0:
+                    continue
+                for j in torch.nonzero(out_ids.view(self.b, -1)[:, 0] < 0).flatten().tolist():   # refused by a matrix-core pass
+                    self.corpus.search_device(q_dev[j:j + 1].contiguous(), self.k, self.eta, self.pref,
+                                              out_ids.view(self.b, -1)[j:j + 1], out_scores.view(self.b, -1)[j:j + 1],
+                                              candidates=self.c if self._explicit_c else None)
+            torch.cuda.current_stream().synchronize()
 
 
 def merge_rerank_device(lists, n_candidates: int, k: int, eta: float, entropy_pref: float, out_ids=None,

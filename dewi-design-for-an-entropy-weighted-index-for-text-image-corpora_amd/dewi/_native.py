@@ -31,7 +31,7 @@ MODE_CODES = {"standard": 0, "conditional": 1}
 #: similarity the ANN-semantics re-rank blends (include/dewi_hip.h DEWI_SIM_*; reference backends.py:229-231, 335-338)
 SIM_CODES = {"ip": 0, "one_minus_dist": 1, "inv_one_plus_dist": 2}
 NUM_SIGNALS = 7
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 #: every symbol include/dewi_hip.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = (
@@ -86,7 +86,7 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.dewi_knn_scan.restype = i32
     lib.dewi_knn_scan.argtypes = [vp, i32, i64, i32, vp, i32, i32, i32, vp, sz, vp]
     lib.dewi_knn_finish.restype = i32
-    lib.dewi_knn_finish.argtypes = [vp, sz, i32, i64, i32, i32, i32, i32, f64, f64, vp, vp, i64, vp, vp, vp, vp]
+    lib.dewi_knn_finish.argtypes = [vp, sz, i32, i64, i32, i32, i32, i32, i32, f64, f64, vp, vp, i64, vp, vp, vp, vp]
     lib.dewi_knn_candidates.restype = i32
     lib.dewi_knn_candidates.argtypes = [vp, i32, i64, i32, vp, i32, vp, vp, i32, i32, i64, vp, vp, sz, vp]
     lib.dewi_merge_rerank.restype = i32

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DEWI_ABI_VERSION 2
+#define DEWI_ABI_VERSION 3
 
 /* status codes */
 #define DEWI_OK 0
@@ -138,21 +138,24 @@ int dewi_knn_rerank_candidates(const void* d_E, int elem_type, int64_t n_rows, i
 int dewi_prepare_queries_bf16(const float* d_Q, int n_queries, int dim, int space, uint16_t* d_out, void* stream);
 
 /* The same search split at the kernel boundary, for callers that keep several queries in flight:
- * dewi_knn_scan enqueues steps 1-3a (corpus scan, per-workgroup candidate lists -> workspace) and
- * dewi_knn_finish steps 3b-5 (select, blend, top-k) from that workspace.  The two may be enqueued on
- * DIFFERENT streams (order them with events) so that the finish of query i overlaps the scan of
- * query i+1 on a second workspace; dewi_knn_rerank_f32 == scan + finish on one stream.
+ * dewi_knn_scan enqueues steps 1-3a (corpus scan, per-workgroup candidate lists or survivor segments ->
+ * workspace) and dewi_knn_finish steps 3b-5 (select, blend, top-k) from that workspace.  The two may be
+ * enqueued on DIFFERENT streams (order them with events) so that the finish of batch i overlaps the scan of
+ * batch i+1 on a second workspace; dewi_knn_rerank_* == scan + finish on one stream, on the same kernels: a
+ * batch takes the same path (row kernels / matrix-core passes) either way, so a query of a matrix-core batch
+ * whose survivor buffer overflowed comes back marked (id -1; records: id -2) here too.
  * dewi_knn_finish writes final results (d_out_cand == NULL) or, for doc-id shards, the shard's
  * `n_candidates` best rows as dewi_candidate records (d_out_cand != NULL; d_out_ids/scores unused,
- * k ignored), exactly as dewi_knn_candidates.  elem_type/n_rows/dim/n_queries/n_candidates must equal
- * the values given to dewi_knn_scan (they determine the workspace layout).  elem_type: 0 fp32, 1 bf16. */
+ * k ignored), exactly as dewi_knn_candidates.  elem_type/n_rows/dim/n_queries/n_candidates/space must equal
+ * the values given to dewi_knn_scan, and both calls must come from the same host thread's tuning (together
+ * they determine the path and the workspace layout).  elem_type: 0 fp32, 1 bf16.  (ABI 3: `space` added.) */
 int dewi_knn_scan(const void* d_E, int elem_type, int64_t n_rows, int dim, const float* d_Q, int n_queries,
                   int n_candidates, int space, void* d_workspace, size_t workspace_bytes, void* stream);
 
 int dewi_knn_finish(const void* d_workspace, size_t workspace_bytes, int elem_type, int64_t n_rows, int dim,
-                    int n_queries, int n_candidates, int k, double eta, double entropy_pref, const float* d_dewi32,
-                    const float* d_ent32, int64_t id_offset, int64_t* d_out_ids, float* d_out_scores,
-                    dewi_candidate* d_out_cand, void* stream);
+                    int n_queries, int n_candidates, int space, int k, double eta, double entropy_pref,
+                    const float* d_dewi32, const float* d_ent32, int64_t id_offset, int64_t* d_out_ids,
+                    float* d_out_scores, dewi_candidate* d_out_cand, void* stream);
 
 /* Same contract with a bf16 corpus (rows already normalised in fp32, then rounded to bf16); queries
  * arrive as fp32, are normalised in fp32 and rounded to bf16; products are exact, accumulation fp32. */

@@ -1,0 +1,72 @@
+"""Batched queries on the matrix-core paths: whole-batch time and the event-timed filter pass at 1M x 768 for
+several batch sizes.  Run on the GPU box from the repo root:
+    [DEWI_HIP_LIB=<variant .so>] python3 scripts/probes/batch_probe.py [--bf16] [--k K] [batch sizes...]
+(fp32 corpus: csrc/knn_mfma_f32.hip from 5 queries; --bf16: depth pass up to 32 queries, 256-query kernel above.)
+"""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, "dewi-design-for-an-entropy-weighted-index-for-text-image-corpora_amd")
+from dewi import _engine as eng  # noqa: E402
+
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev)
+g.manual_seed(42)
+args = sys.argv[1:]
+bf16 = "--bf16" in args
+if bf16:
+    args.remove("--bf16")
+pipelined = "--pipelined" in args      # PipelinedSearcher, two scan streams: consecutive batches overlap their small kernels
+if pipelined:
+    args.remove("--pipelined")
+k = 10
+if "--k" in args:
+    i = args.index("--k")
+    k = int(args[i + 1])
+    del args[i:i + 2]
+n, d = 1_000_000, 768
+emb = torch.randn((n, d), generator=g, device=dev)
+emb /= emb.norm(dim=1, keepdim=True)
+c = eng.DeviceCorpus(emb, torch.rand(n, device=dev), torch.rand(n, device=dev), "cosine")
+if bf16:
+    c = c.to_bf16()
+    del emb
+elem = 2 if bf16 else 4
+sizes = [int(a) for a in args] or [8, 32, 64, 256]
+for b in sizes:
+    Q = torch.randn((8, b, d), generator=g, device=dev)
+    for i in range(5):
+        c.search_device(Q[i % 8], k, 0.3, 0.0)
+    torch.cuda.synchronize()
+    reps = 60
+    t0 = time.perf_counter()
+    for i in range(reps):
+        c.search_device(Q[i % 8], k, 0.3, 0.0)
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / reps
+    eng.timing(1)
+    for i in range(20):
+        c.search_device(Q[i % 8], k, 0.3, 0.0)
+    torch.cuda.synchronize()
+    ms, cnt = eng.timing_read()
+    eng.timing(0)
+    ids, _ = c.search_device(Q[0], k, 0.3, 0.0)
+    if pipelined:
+        for streams in (1, 2, 3):
+            ps = eng.PipelinedSearcher(c, k, 0.3, 0.0, n_queries=b, depth=4, scan_streams=streams)
+            oi = torch.empty((8, b, k), dtype=torch.int64, device=dev)
+            osc = torch.empty((8, b, k), dtype=torch.float32, device=dev)
+            for i in range(8):
+                ps.submit(Q[i % 8], oi[i % 8], osc[i % 8])
+            ps.drain()
+            t0 = time.perf_counter()
+            for i in range(reps):
+                ps.submit(Q[i % 8], oi[i % 8], osc[i % 8])
+            ps.drain()
+            tp = (time.perf_counter() - t0) / reps
+            same = bool(torch.equal(oi[0], ids))
+            print(f"        pipelined, {streams} scan stream(s): {tp * 1e3:.4f} ms per batch  ids equal {same}", flush=True)
+    print(f"B={b:4d} batch {t * 1e3:.4f} ms  filter pass {ms:.4f} ms x {cnt // 20} per batch"
+          f"  ({n * d * elem / ms / 1e6:.0f} GB/s)  refused {int((ids[:, 0] < 0).sum())}", flush=True)

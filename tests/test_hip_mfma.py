@@ -82,3 +82,40 @@ def test_mfma_overflow_falls_back_to_exact_path():
     assert np.array_equal(ids, ids_raw) and np.array_equal(sc, sc_raw)
     assert ids[5].tolist() == [7] + list(range(50_000, 50_009))      # ties: lower rows first
     assert np.allclose(sc[5], 1.0, atol=1e-2)
+
+
+@pytest.mark.parametrize("bf16,b", [(True, 40), (True, 8), (False, 12)])
+def test_pipelined_batches_take_the_matrix_core_paths_and_equal_the_one_call_search(bf16, b):
+    """dewi_knn_scan + dewi_knn_finish (two streams, rotating workspaces) choose the same path as the one-call
+    search for a query batch — 256-query kernel, depth-split pass over a bf16 / an fp32 corpus — so the answers are
+    bit-equal; a refused query of a pipelined batch is answered again by ``drain``; shard records keep the marker."""
+    from dewi import _engine as eng
+    import torch
+    n, dim, k = 100_000, 256, 10
+    raw = orc.synth_corpus(n, dim, seed=3)
+    raw[50_000:90_000] = raw[7]
+    cols = orc.synth_payload_columns(n, seed=3)
+    c = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    if bf16:
+        c = c.to_bf16()
+    Q = orc.synth_queries(3 * b, dim, seed=4).reshape(3, b, dim)
+    Q[1, 5] = raw[7]                                  # batch 1, query 5 overflows its survivor segments
+    q_dev = torch.from_numpy(Q).cuda()
+    want = [c.search(Q[i], k, 0.3, 0.1) for i in range(3)]          # blocking API: repaired
+    raw_ids, _ = c.search_device(q_dev[1], k, 0.3, 0.1)
+    assert (raw_ids[5] == -1).all().item()                          # the one-call search refuses it too
+    pipe = eng.PipelinedSearcher(c, k, 0.3, 0.1, n_queries=b, depth=3, scan_streams=2)
+    ids = torch.empty((3, b, k), dtype=torch.int64, device="cuda")
+    sc = torch.empty((3, b, k), dtype=torch.float32, device="cuda")
+    for rounds in range(2):                                         # workspaces and output buffers reused
+        for i in range(3):
+            pipe.submit(q_dev[i], ids[i], sc[i])
+    pipe.drain()
+    for i in range(3):
+        assert np.array_equal(ids[i].cpu().numpy(), want[i][0]) and np.array_equal(sc[i].cpu().numpy(), want[i][1])
+    recs = torch.empty((b, 2 * k, 4), dtype=torch.int32, device="cuda")
+    pipe2 = eng.PipelinedSearcher(c, k, 0.3, 0.1, n_queries=b, n_candidates=2 * k)
+    pipe2.submit(q_dev[1], out_records=recs)
+    pipe2.drain()
+    assert torch.equal(recs, c.candidates_device(q_dev[1], 2 * k))
+    assert (recs[5, :, 3] == -2).all().item()
