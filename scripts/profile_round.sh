@@ -4,6 +4,7 @@
 # 1. rocprofv3 --kernel-trace --stats of the default bench command (c2), of --config c3 and --config c5
 # 2. PMC passes, ONE COUNTER SET PER RUN and never together with a trace domain: FETCH_SIZE, WRITE_SIZE (c2, c3),
 #    then the SQ counters of the matrix-core kernel (c3): LDS bank conflicts, MFMA / VALU busy, wait cycles
+#    and of the fp32 depth-split pass (32 queries, scripts/probes/batch_probe.py): FETCH_SIZE, MFMA / VALU busy, LDS
 # 3. scripts/summarize_pmc.py -> pmc_summary.{txt,json} and hbm_traffic.json (bench.py's roofline.traffic)
 # The program itself (python3 bench.py) follows `--` directly: no env/bash hop under the profiler.
 set -e
@@ -27,6 +28,20 @@ pmc() {     # dir suffix, counters (space separated in one string), bench args..
     echo "pmc pass $name FAILED (counter set: $ctr)"; tail -5 $OUT/pmc_$name.err
   fi
 }
+probe_trace() {   # name, probe args...
+  local name=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$name -o bench -- python3 scripts/probes/batch_probe.py "$@" > $OUT/probe_under_trace_$name.txt 2> $OUT/trace_$name.err || { tail -20 $OUT/trace_$name.err; exit 1; }
+  find $OUT/trace_$name -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_$name.csv
+  head -8 $OUT/kernel_stats_$name.csv
+}
+probe_pmc() {     # dir suffix, counters, probe args...
+  local name=$1; local ctr=$2; shift; shift
+  if rocprofv3 --pmc $ctr --output-format csv -d $OUT/pmc_$name -o bench -- python3 scripts/probes/batch_probe.py "$@" > $OUT/probe_under_pmc_$name.txt 2> $OUT/pmc_$name.err; then
+    echo "pmc pass $name done"
+  else
+    echo "pmc pass $name FAILED (counter set: $ctr)"; tail -5 $OUT/pmc_$name.err
+  fi
+}
 trace c2 --steps 300 --warmup 30
 trace c3 --config c3 --steps 40 --warmup 5
 trace c5 --config c5 --steps 20 --warmup 3
@@ -37,5 +52,9 @@ pmc WRITE_SIZE_c3 WRITE_SIZE --config c3 --steps 10 --warmup 2
 pmc SQ_LDS_c3 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES" --config c3 --steps 10 --warmup 2
 pmc SQ_MFMA_c3 "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_COEXEC_CYCLES" --config c3 --steps 10 --warmup 2
 pmc SQ_WAIT_c3 "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" --config c3 --steps 10 --warmup 2
+probe_trace f32b32 32
+probe_pmc FETCH_SIZE_f32b32 FETCH_SIZE 32
+probe_pmc SQ_MFMA_f32b32 "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" 32
+probe_pmc SQ_LDS_f32b32 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" 32
 python3 scripts/summarize_pmc.py $OUT --commit $COMMIT --record "1000000x768x4xB1=scan_rows_f32" "1000000x768x2xB256=mfma_scan_bf16_s16<48, false>" > $OUT/pmc_summary.txt
 cat $OUT/pmc_summary.txt
