@@ -195,3 +195,25 @@ def test_batch_api_equals_single_queries():
     index.add("late", embs[0], pays[0])            # add after build -> lazily rebuilt
     assert index.search(embs[0], k=2, eta=0.0)[0][0] in ("doc_0", "late")
     assert len(index) == N_DOCS + 1
+
+
+@pytest.mark.parametrize("flag", [None, "--objects", "--per-row-add"])
+def test_profile_harness_writes_the_reference_metrics_layout(tmp_path, flag):
+    """scripts/profile_index.py — the reference harness's command line (reference scripts/profile_index.py:239-292)
+    on this package — run as the reference's users run it: one child process, metrics.json with the reference's
+    sections and keys, every ingest mode (columns, Payload objects, one add() per document)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parent.parent
+    cmd = [sys.executable, str(repo / "scripts" / "profile_index.py"), "--n-docs", "3000", "--dim", "128",
+           "--n-queries", "40", "--k", "10", "--output", str(tmp_path / "prof")]
+    if flag:
+        cmd.append(flag)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    m = json.loads((tmp_path / "prof" / "metrics.json").read_text())
+    assert set(m) == {"build", "search"}
+    assert {"n_docs", "dim", "data_generation_time", "index_construction_time", "docs_per_second"} <= set(m["build"])
+    assert set(m["search"]) == {"n_queries", "k", "total_search_time", "queries_per_second", "latency_ms"}
+    assert m["build"]["n_docs"] == 3000 and m["search"]["n_queries"] == 40 and m["search"]["queries_per_second"] > 0
