@@ -34,6 +34,7 @@ if bf16:
     c = c.to_bf16()
     del emb
 elem = 2 if bf16 else 4
+args = [a for a in args if a != "--graph"]
 sizes = [int(a) for a in args] or [8, 32, 64, 256]
 for b in sizes:
     Q = torch.randn((8, b, d), generator=g, device=dev)
@@ -53,6 +54,28 @@ for b in sizes:
     ms, cnt = eng.timing_read()
     eng.timing(0)
     ids, _ = c.search_device(Q[0], k, 0.3, 0.0)
+    if "--graph" in sys.argv:
+        # the batch's five kernels replayed from a captured graph: what the dependent-launch gaps cost
+        oi = torch.empty((b, k), dtype=torch.int64, device=dev)
+        osc = torch.empty((b, k), dtype=torch.float32, device=dev)
+        qbuf = Q[0].clone()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            c.search_device(qbuf, k, 0.3, 0.0, oi, osc)
+            side.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                c.search_device(qbuf, k, 0.3, 0.0, oi, osc)
+            for i in range(5):
+                graph.replay()
+            side.synchronize()
+            t0 = time.perf_counter()
+            for i in range(reps):
+                graph.replay()
+            side.synchronize()
+            tg = (time.perf_counter() - t0) / reps
+        same = bool(torch.equal(oi, ids))
+        print(f"        graph replay: {tg * 1e3:.4f} ms per batch  ids equal {same}", flush=True)
     if pipelined:
         for streams in (1, 2, 3):
             ps = eng.PipelinedSearcher(c, k, 0.3, 0.0, n_queries=b, depth=4, scan_streams=streams)
