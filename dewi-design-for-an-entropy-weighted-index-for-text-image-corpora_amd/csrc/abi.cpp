@@ -200,8 +200,9 @@ int check_common(const void* d_E, int64_t n_rows, int dim, const float* d_Q, int
 // chosen from the shapes alone so that dewi_knn_scan and dewi_knn_finish (two calls, two streams) agree:
 //   Rows  : row-per-wave kernels, 1 / 4 / 8 queries per corpus pass (any shape, any space)
 //   Depth : depth-split matrix-core pass, 32 queries per corpus pass (fp32 corpus from 5 queries; bf16 corpus for
-//           2..32 queries, and for larger batches where the 256-query kernel cannot hold the dimension)
-//   Big   : 256-query matrix-core kernel (bf16 corpus, dim <= 768, more than 32 queries)
+//           2..32 queries, and for larger batches where the 256-query kernel cannot hold the dimension or the space
+//           is l2); cosine and l2
+//   Big   : 256-query matrix-core kernel (bf16 corpus, cosine, dim <= 768, more than 32 queries)
 enum class BatchPath { Rows, Depth, Big };
 struct BatchPlan {
   BatchPath path;
@@ -427,7 +428,7 @@ int dewi_prepare_queries_bf16(const float* d_Q, int n_queries, int dim, int spac
   if (!d_Q || !d_out) return fail(DEWI_ERR_INVALID_ARG, "null pointer");
   if (n_queries <= 0 || dim <= 0) return fail(DEWI_ERR_INVALID_ARG, "non-positive size");
   if (space != DEWI_SPACE_COSINE && space != DEWI_SPACE_L2) return fail(DEWI_ERR_INVALID_ARG, "unknown space %d", space);
-  hipError_t e = dewi::launch_prepare_queries_bf16(d_Q, d_out, n_queries, n_queries, dim, space, static_cast<hipStream_t>(stream));
+  hipError_t e = dewi::launch_prepare_queries_bf16(d_Q, d_out, n_queries, n_queries, dim, space, nullptr, static_cast<hipStream_t>(stream));
   return e == hipSuccess ? DEWI_OK : hip_fail(e, "prepare_queries_bf16 launch");
 }
 

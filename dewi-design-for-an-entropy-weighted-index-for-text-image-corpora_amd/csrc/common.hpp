@@ -70,6 +70,12 @@ __device__ __forceinline__ float wave_query_norm(double ss) {
   for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, kWave);
   return static_cast<float>(__dsqrt_rn(ss));
 }
+// Sum of a float64 over the wave, bit-identical in all 64 lanes (xor butterfly as above).
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
 __device__ __forceinline__ double square_f64(float v) { return static_cast<double>(v) * static_cast<double>(v); }
 
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {

@@ -110,15 +110,19 @@ using LdsPtr = void __attribute__((address_space(3)))*;
 
 // Query preparation: normalise (cosine, unless the norm is 0) and round to bf16; rows >= n_queries
 // of the 32-padded block are zero.  One wave per query row.
+// qn2 (optional): ||bf16-rounded prepared query||^2 per output row (float64-summed, one rounding), for the l2 score of
+// the depth-split pass.
 __global__ __launch_bounds__(kWave) void prepare_queries_bf16(const float* __restrict__ Q, uint16_t* __restrict__ Qb,
-                                                              int n_queries, int dim, int space) {
+                                                              int n_queries, int dim, int space, float* __restrict__ qn2) {
   const int lane = lane_id();
   const int row = static_cast<int>(blockIdx.x);
   uint16_t* o = Qb + static_cast<int64_t>(row) * dim;
   if (row >= n_queries) {
     for (int j = lane; j < dim; j += kWave) o[j] = 0;
+    if (qn2 != nullptr && lane == 0) qn2[row] = 0.f;
     return;
   }
+  auto widen = [](uint16_t b) { return __uint_as_float(static_cast<uint32_t>(b) << 16); };
   const float* q = Q + static_cast<int64_t>(row) * dim;
   auto to_bf16 = [](float v) {
     const uint32_t u = __float_as_uint(v);
@@ -146,6 +150,7 @@ __global__ __launch_bounds__(kWave) void prepare_queries_bf16(const float* __res
       norm = wave_query_norm(ss);
       scale = norm > 0.f;
     }
+    double out2 = 0.0;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int j = lane + u * kWave;
@@ -155,8 +160,13 @@ __global__ __launch_bounds__(kWave) void prepare_queries_bf16(const float* __res
         r.y = to_bf16(scale ? __fdiv_rn(v[u].y, norm) : v[u].y);
         r.z = to_bf16(scale ? __fdiv_rn(v[u].z, norm) : v[u].z);
         r.w = to_bf16(scale ? __fdiv_rn(v[u].w, norm) : v[u].w);
+        out2 += square_f64(widen(r.x)) + square_f64(widen(r.y)) + square_f64(widen(r.z)) + square_f64(widen(r.w));
         reinterpret_cast<u16x4p*>(o)[j] = r;
       }
+    }
+    if (qn2 != nullptr) {
+      out2 = wave_sum_f64(out2);
+      if (lane == 0) qn2[row] = static_cast<float>(out2);
     }
     return;
   }
@@ -168,7 +178,16 @@ __global__ __launch_bounds__(kWave) void prepare_queries_bf16(const float* __res
     norm = wave_query_norm(ss);
     scale = norm > 0.f;
   }
-  for (int j = lane; j < dim; j += kWave) o[j] = to_bf16(scale ? __fdiv_rn(q[j], norm) : q[j]);
+  double out2 = 0.0;
+  for (int j = lane; j < dim; j += kWave) {
+    const uint16_t r = to_bf16(scale ? __fdiv_rn(q[j], norm) : q[j]);
+    out2 += square_f64(widen(r));
+    o[j] = r;
+  }
+  if (qn2 != nullptr) {
+    out2 = wave_sum_f64(out2);
+    if (lane == 0) qn2[row] = static_cast<float>(out2);
+  }
 }
 
 // KS = dim / 16 MFMA k-steps (dim % 128 == 0, dim <= 768).
@@ -1071,8 +1090,8 @@ static hipError_t run_mfma_dim(const MfmaLayout& m, const uint16_t* E, int64_t n
 }
 
 hipError_t launch_prepare_queries_bf16(const float* d_Q, uint16_t* d_out, int n_queries, int n_rows_out, int dim, int space,
-                                       hipStream_t stream) {
-  hipLaunchKernelGGL(prepare_queries_bf16, dim3(n_rows_out), dim3(kWave), 0, stream, d_Q, d_out, n_queries, dim, space);
+                                       float* d_qn2, hipStream_t stream) {
+  hipLaunchKernelGGL(prepare_queries_bf16, dim3(n_rows_out), dim3(kWave), 0, stream, d_Q, d_out, n_queries, dim, space, d_qn2);
   return hipGetLastError();
 }
 
@@ -1080,7 +1099,7 @@ hipError_t launch_mfma_bf16(const MfmaLayout& m, const uint16_t* d_E, int64_t n_
                             int n_queries, int n_candidates, int space, char* ws, int compute_units,
                             hipStream_t stream) {
   hipLaunchKernelGGL(prepare_queries_bf16, dim3(m.q_pad), dim3(kWave), 0, stream, d_Q,
-                     reinterpret_cast<uint16_t*>(ws + m.qb_off), n_queries, dim, space);
+                     reinterpret_cast<uint16_t*>(ws + m.qb_off), n_queries, dim, space, static_cast<float*>(nullptr));
   switch (dim / 16) {
     case 8: return run_mfma_dim<8>(m, d_E, n_rows, n_queries, n_candidates, ws, compute_units, stream);
     case 16: return run_mfma_dim<16>(m, d_E, n_rows, n_queries, n_candidates, ws, compute_units, stream);

@@ -20,6 +20,17 @@
 // 0.445-0.48 ms (6.4-6.9 TB/s).  Dim 1536 would need 144 registers of query pieces per lane and keeps
 // v_mfma_f32_32x32x2_f32 on the fp32 values (exact products, an fmaf chain per depth slice).
 //
+// SPACE l2 (reference backends.py:434-436, -sum((E - q)^2)): scored as 2<e,q> - ||e||^2 - ||q||^2.  <e,q> is the
+// same matrix product on the raw rows and raw (bf16 corpus: bf16-rounded) queries; ||q||^2 comes float64-summed
+// from the query preparation kernel; ||e||^2 is summed in this kernel from the very fragments it multiplies (16
+// fmas per chunk and lane, shares of the 8 waves x 2 lane halves exchanged through the spare slot of the reduction
+// buffer and summed in a fixed order), so the corpus is still read once and nothing is stored per row.  The three
+// terms round at the magnitude of ||e||^2 + ||q||^2 (an ulp of the result, as the reference's own fp32 sum does);
+// tests/test_hip_mfma_f32.py compares with the oracle at gaps and tolerances scaled by that magnitude.  fp32
+// corpora: dims up to 768 (beyond, query pieces + norm traffic do not fit the registers: such batches keep the
+// row-per-wave l2 kernels); bf16 corpora: every supported dim.  1 M x 768: fp32 32 queries 0.49 ms per pass
+// (cosine 0.47), bf16 0.225 ms — l2 batches used to cost a row-kernel pass per 4 (fp32) queries.
+//
 // Roofline: HBM.  Algorithmic bytes per pass = n_rows * dim * 4 (the corpus read once), 0.38 ms at
 // 8 TB/s for 1M x 768; flops = 6 * 2 * 32 * n_rows * dim bf16 (0.29 PFLOP) = 0.12 ms at 2.5 PFLOP/s.
 //
@@ -76,6 +87,7 @@ struct DepthGeo {
   static constexpr int kReads = BF16 ? 2 : 4;                         // ds_read_b128 per wave and chunk (== kPieces)
   static constexpr int kWaitPieces = (kRing - 2) * kPieces;           // vmcnt that leaves chunk g+1 landed: 8 / 12
 };
+constexpr int kF32MaxL2Chunks = 3;                                  // fp32 corpus, l2 space: dims up to 768 (CH = 4 spills 12 bytes per lane)
 constexpr int kF32RedRegs = 15;                                     // LDS slots per wave: the 14 registers it hands over + a spare
 constexpr int kF32RedBytes = kF32Waves * kF32RedRegs * kWave * 4;   // 30 KiB
 template <bool BF16>
@@ -119,12 +131,16 @@ __device__ __forceinline__ void split3(const u32x4f& x0, const u32x4f& x1, u32x4
 //         the best score this lane's register e saw over the workgroup's tiles (32 group maxima per workgroup).
 // filter: raw records out[(blockIdx.x * 32 + q) * out_stride + slot], cnt[blockIdx.x * 32 + q] = records offered.
 // BF16: E and Qn are bf16 (Qn prepared by prepare_queries_bf16); otherwise fp32.
-template <bool BF16, int CH, bool SAMPLE>
+// L2: the score is -||e - q||^2 (reference backends.py:434-436) in the form 2<e,q> - ||e||^2 - ||q||^2: Qn holds the raw
+//     (bf16 corpus: bf16-rounded) queries, qn2 their squared norms, and ||e||^2 is summed here from the very fragments
+//     that are multiplied (see "row norms" below).
+template <bool BF16, int CH, bool SAMPLE, bool L2>
 __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __restrict__ E, int64_t n_rows,
                                                                 const void* __restrict__ Qn, int64_t n_tiles,
                                                                 int64_t tile_stride, const float* __restrict__ thr,
                                                                 uint64_t* __restrict__ out, int64_t out_stride,
-                                                                uint32_t* __restrict__ cnt, int n_active) {
+                                                                uint32_t* __restrict__ cnt, int n_active,
+                                                                const float* __restrict__ qn2) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using G = DepthGeo<BF16>;
   constexpr int DIM = CH * kF32ChunkCols;
@@ -160,6 +176,7 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
     }
   }
   const float thr_l = SAMPLE ? -__builtin_inff() : (r < n_active ? thr[r] : __builtin_inff());
+  const float qn2_l = L2 ? qn2[r] : 0.f;
   // pin the waits for these loads here, before any DMA is in flight (a compiler-inserted vmcnt(0) inside the
   // chunk loop would drain the ring on every iteration)
 #pragma unroll
@@ -167,7 +184,7 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
 #pragma unroll
     for (int m = 0; m < kQRegs; ++m) asm volatile("" ::"v"(qf[ch][m]));
   }
-  asm volatile("" ::"v"(thr_l));
+  asm volatile("" ::"v"(thr_l), "v"(qn2_l));
   if (!SAMPLE && threadIdx.x < kF32Queries) lcnt[threadIdx.x] = 0;   // read first at a tile end, behind several barriers
 
   // ---- DMA.  The 16-byte unit u of a chunk row lands at LDS unit u ^ (row & 15), i.e. the lane that fills LDS
@@ -241,11 +258,37 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
   // to the spare slot 14 (never read), which keeps the stores free of branches
   const uint32_t red_addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((LdsPtrF)(red))) + 4u * static_cast<uint32_t>(lane);
   float own0 = 0.f, own1 = 0.f;
+  // ROW NORMS (L2).  Lane (r, h) sees 16 of row r's 256 columns per chunk; their squares are summed into nrm_a / nrm_b (
+  // fmas, fixed order) over the tile's chunks, and the lane's share of ||e_r||^2 goes to its place in the wave's spare
+  // slot 14, BEHIND the two placeholder stores of the loop below (LDS operations of a wave execute in order).
+  // Stage 2 sums the sixteen shares of a row (eight waves x two lane halves) in a fixed order.
+  // (scalar fmas on two accumulators: __builtin_elementwise_fma on a float2 came out of hipcc 7.2 as v_pk_fma_f32 pairs
+  // with op_sel_hi:[0,0,1] that add the LOW element's square to both halves — wrong sums)
+  float nrm_a = 0.f, nrm_b = 0.f;
+  auto add_squares = [&](const u32x4f& x) {
+#pragma unroll
+    for (int i = 0; i < (BF16 ? 4 : 2); ++i) {
+      float va, vb;
+      if constexpr (BF16) {
+        va = __uint_as_float(x[i] << 16);
+        vb = __uint_as_float(x[i] & 0xffff0000u);
+      } else {
+        va = __uint_as_float(x[2 * i]);
+        vb = __uint_as_float(x[2 * i + 1]);
+      }
+      nrm_a = __builtin_fmaf(va, va, nrm_a);
+      nrm_b = __builtin_fmaf(vb, vb, nrm_b);
+    }
+  };
   auto stage1_store = [&](const f32x16f& acc) {     // hand the other waves their registers of this wave's partial block
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int sl = j < 2 * w ? j : (j > 2 * w + 1 ? j - 2 : 14);
       asm volatile("ds_write_b32 %0, %1" ::"v"(red_addr + static_cast<uint32_t>((w * kF32RedRegs + sl) * kWave * 4)), "v"(acc[j]) : "memory");
+    }
+    if constexpr (L2) {
+      const float rown = nrm_a + nrm_b;              // this lane's half (h) of the wave's share of ||e_r||^2
+      asm volatile("ds_write_b32 %0, %1" ::"v"(red_addr + static_cast<uint32_t>((w * kF32RedRegs + 14) * kWave * 4)), "v"(rown) : "memory");
     }
 #pragma unroll
     for (int ww = 0; ww < kF32Waves; ++ww) {
@@ -256,6 +299,9 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
     }
   };
   float part[kF32Waves][2];
+  // documents of registers 2w, 2w+1 inside the tile: 2 (w & 1) + 8 (w >> 1) + 4 h and the next row
+  const uint32_t nrm_addr = red_addr - 4u * static_cast<uint32_t>(lane) +
+                            4u * static_cast<uint32_t>(2 * (w & 1) + 8 * (w >> 1) + 4 * h);
   auto stage2_load = [&]() {                         // registers 2w, 2w+1 of every wave's partial block (own: spare slot)
 #pragma unroll
     for (int v = 0; v < kF32Waves; ++v) {
@@ -265,6 +311,12 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
         const int sl = v == w ? 14 : (w < v ? j : j - 2);
         asm volatile("ds_read_b32 %0, %1" : "=v"(part[v][e]) : "v"(red_addr + static_cast<uint32_t>((v * kF32RedRegs + sl) * kWave * 4)));
       }
+    }
+  };
+  auto stage2_pin = [&]() {                          // the loads above are complete (callers wait lgkmcnt(0) first)
+#pragma unroll
+    for (int v = 0; v < kF32Waves; ++v) {
+      asm volatile("" : "+v"(part[v][0]), "+v"(part[v][1]));
     }
   };
   float mx0 = -__builtin_inff(), mx1 = -__builtin_inff();
@@ -302,6 +354,37 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
       const float p0 = v == w ? own0 : part[v][0], p1 = v == w ? own1 : part[v][1];
       s0 = v == 0 ? p0 : s0 + p0;
       s1 = v == 0 ? p1 : s1 + p1;
+    }
+    if constexpr (L2) {                                // -||e - q||^2 = 2 <e,q> - ||e||^2 - ||q||^2, one rounding per step
+      // the eight shares of ||e||^2 of this lane's two documents, read here (not with the partial sums at the top of
+      // the chunk: sixteen more live registers through the MFMA block would spill at dim 1024) and summed in wave order
+      float n0 = 0.f, n1 = 0.f;
+#pragma unroll
+      for (int pair = 0; pair < 4; ++pair) {           // two waves' shares (two lane halves each) at a time: eight transient registers
+        float np[2][2][2];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+              asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(np[v][hh][e])      // one address register, immediate offsets
+                           : "v"(nrm_addr), "n"(((2 * pair + v) * kF32RedRegs + 14) * kWave * 4 + 128 * hh + 4 * e));
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            asm volatile("" : "+v"(np[v][hh][0]), "+v"(np[v][hh][1]));
+            n0 = (pair == 0 && v == 0 && hh == 0) ? np[v][hh][0] : n0 + np[v][hh][0];
+            n1 = (pair == 0 && v == 0 && hh == 0) ? np[v][hh][1] : n1 + np[v][hh][1];
+          }
+        }
+      }
+      s0 = (2.f * s0 - n0) - qn2_l;
+      s1 = (2.f * s1 - n1) - qn2_l;
     }
     const int64_t row0 = (first + it * step) * tile_stride * kF32TileRows;
     const int64_t doc = row0 + 2 * (w & 1) + 8 * (w >> 1) + 4 * h;     // register 2w; register 2w+1 is the next row
@@ -371,6 +454,11 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
         for (int p = 0; p < 2; ++p) {
           u32x4f ah, am, al;
           split3(cur[2 * p], cur[2 * p + 1], ah, am, al);
+          if constexpr (L2) {
+            if (ch == 0 && p == 0) nrm_a = nrm_b = 0.f;
+            add_squares(cur[2 * p]);
+            add_squares(cur[2 * p + 1]);
+          }
           auto mm = [&](const u32x4f& a, const u32x4f& b, bool first) {
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8f, a), __builtin_bit_cast(bf16x8f, b),
                                                           first ? zero : acc, 0, 0, 0);
@@ -391,6 +479,10 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
       } else {
 #pragma unroll
         for (int m = 0; m < G::kReads; ++m) {
+          if constexpr (L2) {
+            if (ch == 0 && m == 0) nrm_a = nrm_b = 0.f;
+            add_squares(cur[m]);
+          }
           if constexpr (BF16) {
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8f, cur[m]), __builtin_bit_cast(bf16x8f, qf[ch][m]),
                                                           (ch == 0 && m == 0) ? zero : acc, 0, 0, 0);
@@ -410,8 +502,7 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
       // chunk g+1's fragments (and the previous tile's partials) are in registers
       reads_done(nxt);
       if (finish_prev) {
-#pragma unroll
-        for (int v = 0; v < kF32Waves; ++v) asm volatile("" : "+v"(part[v][0]), "+v"(part[v][1]));
+        stage2_pin();
         stage2_finish(it - 1);
       }
 #pragma unroll
@@ -433,8 +524,7 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
     asm volatile("" ::: "memory");
     stage2_load();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int v = 0; v < kF32Waves; ++v) asm volatile("" : "+v"(part[v][0]), "+v"(part[v][1]));
+    stage2_pin();
     stage2_finish(n_my - 1);
     if constexpr (!SAMPLE) flush_pending();
   }
@@ -457,8 +547,9 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
 bool mfma_f32_path_supported(int elem_type, int64_t n_rows, int dim, int n_queries, int n_candidates, int space) {
   const int ch = dim / kF32ChunkCols;
   const int min_q = elem_type ? kMfmaMinQueries : kMfmaF32MinQueries;
-  return space == DEWI_SPACE_COSINE && n_queries >= min_q && dim % kF32ChunkCols == 0 && ch >= 1 && ch <= 6 && ch != 5 &&
-         n_rows >= 64 * 1024 && n_candidates <= 256;
+  if (space == DEWI_SPACE_L2 && elem_type == 0 && ch > kF32MaxL2Chunks) return false;   // fp32 rows beyond 768 columns: query pieces + row norms do not fit the registers
+  return (space == DEWI_SPACE_COSINE || space == DEWI_SPACE_L2) && n_queries >= min_q && dim % kF32ChunkCols == 0 && ch >= 1 &&
+         ch <= 6 && ch != 5 && n_rows >= 64 * 1024 && n_candidates <= 256;
 }
 
 MfmaF32Layout plan_mfma_f32(int elem_type, int64_t n_rows, int dim, int n_queries, int n_candidates, int compute_units) {
@@ -484,6 +575,7 @@ MfmaF32Layout plan_mfma_f32(int elem_type, int64_t n_rows, int dim, int n_querie
   m.seg_cap = static_cast<int>(cap < 16 ? 16 : cap);
   size_t off = 0;
   m.qn_off = off;      off += up(static_cast<size_t>(m.q_pad) * dim * (elem_type ? 2 : 4));
+  m.qn2_off = off;     off += up(static_cast<size_t>(m.q_pad) * 4);
   m.thr_off = off;     off += up(static_cast<size_t>(m.q_pad) * 4);
   m.cnt_off = off;     off += up(static_cast<size_t>(m.groups) * m.n_seg * kF32Queries * 4);
   m.dense_off = off;   off += up(static_cast<size_t>(kF32Queries) * m.sample_stride * 4);
@@ -492,21 +584,22 @@ MfmaF32Layout plan_mfma_f32(int elem_type, int64_t n_rows, int dim, int n_querie
   return m;
 }
 
-template <bool BF16, int CH>
+template <bool BF16, int CH, bool L2>
 static hipError_t run_mfma_f32_dim(const MfmaF32Layout& m, const void* E, int64_t n_rows, int n_queries, int n_candidates,
                                    char* ws, hipStream_t stream) {
   constexpr int DIM = CH * kF32ChunkCols;
   constexpr int kLds = depth_lds_bytes<BF16>();
   static PerDeviceOnce attr_once;   // one per instantiation
   const hipError_t ea = attr_once.run([] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan_f32<BF16, CH, true>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan_f32<BF16, CH, true, L2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan_f32<BF16, CH, false>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan_f32<BF16, CH, false, L2>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
   });
   if (ea != hipSuccess) return ea;
   const char* qn = ws + m.qn_off;
+  const float* qn2 = reinterpret_cast<const float*>(ws + m.qn2_off);
   float* thr = reinterpret_cast<float*>(ws + m.thr_off);
   uint32_t* cnt = reinterpret_cast<uint32_t*>(ws + m.cnt_off);
   float* dense = reinterpret_cast<float*>(ws + m.dense_off);
@@ -518,17 +611,18 @@ static hipError_t run_mfma_f32_dim(const MfmaF32Layout& m, const void* E, int64_
     uint64_t* og = cand + static_cast<int64_t>(g) * m.n_seg * kF32Queries * m.seg_cap;
     const int n_active = n_queries - g * kF32Queries < kF32Queries ? n_queries - g * kF32Queries : kF32Queries;
     // 1. group maxima over the strided sample
-    hipLaunchKernelGGL((mfma_scan_f32<BF16, CH, true>), dim3(m.sample_blocks), dim3(kF32Threads), kLds, stream, E, n_rows, qg,
+    const float* q2g = qn2 + g * kF32Queries;
+    hipLaunchKernelGGL((mfma_scan_f32<BF16, CH, true, L2>), dim3(m.sample_blocks), dim3(kF32Threads), kLds, stream, E, n_rows, qg,
                        m.n_sample_tiles, m.tile_stride, static_cast<const float*>(nullptr), reinterpret_cast<uint64_t*>(dense),
-                       m.sample_stride, static_cast<uint32_t*>(nullptr), n_active);
+                       m.sample_stride, static_cast<uint32_t*>(nullptr), n_active, q2g);
     // 2. per-query threshold: the c-th largest group maximum (real queries only)
     const hipError_t et = launch_sample_threshold(dense, m.sample_stride, m.sample_stride, n_candidates, tg, n_active, stream);
     if (et != hipSuccess) return et;
     // 3. the full pass with the filter (the kernel dewi_timing_read reports: algorithmic bytes = n_rows * dim * elem)
     timing_begin(stream);
-    hipLaunchKernelGGL((mfma_scan_f32<BF16, CH, false>), dim3(m.n_blocks), dim3(kF32Threads), kLds, stream, E, n_rows, qg,
+    hipLaunchKernelGGL((mfma_scan_f32<BF16, CH, false, L2>), dim3(m.n_blocks), dim3(kF32Threads), kLds, stream, E, n_rows, qg,
                        m.n_tiles, static_cast<int64_t>(1), static_cast<const float*>(tg), og, static_cast<int64_t>(m.seg_cap), cg,
-                       n_active);
+                       n_active, q2g);
     timing_end(stream);
   }
   return hipGetLastError();
@@ -538,15 +632,24 @@ hipError_t launch_mfma_f32(const MfmaF32Layout& m, int elem_type, const void* d_
                            int n_queries, int n_candidates, int space, char* ws, hipStream_t stream) {
   // normalised queries (fp32, or rounded to bf16 for a bf16 corpus), zero rows behind the real ones (a padding query
   // scores 0 everywhere; its threshold is forced to +inf in the kernel)
+  // (l2: raw queries, rounded to bf16 for a bf16 corpus, and their squared norms)
+  float* qn2 = reinterpret_cast<float*>(ws + m.qn2_off);
   hipError_t e = elem_type ? launch_prepare_queries_bf16(d_Q, reinterpret_cast<uint16_t*>(ws + m.qn_off), n_queries, m.q_pad, dim,
-                                                         space, stream)
+                                                         space, qn2, stream)
                            : launch_prepare_queries_padded(d_Q, reinterpret_cast<float*>(ws + m.qn_off), n_queries, m.q_pad, dim,
-                                                           space, stream);
+                                                           space, qn2, stream);
   if (e != hipSuccess) return e;
-#define DEWI_DEPTH(CH)                                                                                            \
-  case CH:                                                                                                        \
-    return elem_type ? run_mfma_f32_dim<true, CH>(m, d_E, n_rows, n_queries, n_candidates, ws, stream)            \
-                     : run_mfma_f32_dim<false, CH>(m, d_E, n_rows, n_queries, n_candidates, ws, stream);
+  const bool l2 = space == DEWI_SPACE_L2;
+#define DEWI_DEPTH(CH)                                                                                                       \
+  case CH:                                                                                                                   \
+    if (l2) {                                                                                                                \
+      if (elem_type) return run_mfma_f32_dim<true, CH, true>(m, d_E, n_rows, n_queries, n_candidates, ws, stream);          \
+      if constexpr (CH <= kF32MaxL2Chunks)                                                                                   \
+        return run_mfma_f32_dim<false, CH, true>(m, d_E, n_rows, n_queries, n_candidates, ws, stream);                       \
+      return hipErrorInvalidValue;                                                                                           \
+    }                                                                                                                        \
+    return elem_type ? run_mfma_f32_dim<true, CH, false>(m, d_E, n_rows, n_queries, n_candidates, ws, stream)                \
+                     : run_mfma_f32_dim<false, CH, false>(m, d_E, n_rows, n_queries, n_candidates, ws, stream);
   switch (dim / kF32ChunkCols) {
     DEWI_DEPTH(1)
     DEWI_DEPTH(2)

@@ -241,13 +241,17 @@ __global__ __launch_bounds__(kScanThreads) void scan_generic_f32(const float* __
 // ---------------------------------------------------------------------------------------------
 // Query preparation for the generic path: one wave per query, cosine -> q / ||q|| unless 0.
 // ---------------------------------------------------------------------------------------------
+// qn2 (optional): ||prepared query||^2 per output row — float64-summed, one rounding to fp32 — for the l2 score of the
+// matrix-core passes, 2<e,q> - ||e||^2 - ||q||^2.
 __global__ __launch_bounds__(kWave) void prepare_queries_f32(const float* __restrict__ Q, float* __restrict__ Qn,
-                                                             int dim, int space, int to_bf16, int n_real) {
+                                                             int dim, int space, int to_bf16, int n_real,
+                                                             float* __restrict__ qn2) {
   const int lane = lane_id();
   const float* q = Q + static_cast<int64_t>(blockIdx.x) * dim;
   float* o = Qn + static_cast<int64_t>(blockIdx.x) * dim;
   if (static_cast<int>(blockIdx.x) >= n_real) {   // padding row of a 32-query block
     for (int j = lane; j < dim; j += kWave) o[j] = 0.f;
+    if (qn2 != nullptr && lane == 0) qn2[blockIdx.x] = 0.f;
     return;
   }
   auto round_bf16 = [](float v) {   // nearest-even bf16, kept as the fp32 value it represents
@@ -273,6 +277,7 @@ __global__ __launch_bounds__(kWave) void prepare_queries_f32(const float* __rest
       norm = wave_query_norm(ss);
       scale = norm > 0.f;
     }
+    double out2 = 0.0;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int j = lane + u * kWave;
@@ -288,8 +293,13 @@ __global__ __launch_bounds__(kWave) void prepare_queries_f32(const float* __rest
           r.z = round_bf16(r.z);
           r.w = round_bf16(r.w);
         }
+        out2 += square_f64(r.x) + square_f64(r.y) + square_f64(r.z) + square_f64(r.w);
         reinterpret_cast<f32x4*>(o)[j] = r;
       }
+    }
+    if (qn2 != nullptr) {
+      out2 = wave_sum_f64(out2);
+      if (lane == 0) qn2[blockIdx.x] = static_cast<float>(out2);
     }
     return;
   }
@@ -301,21 +311,29 @@ __global__ __launch_bounds__(kWave) void prepare_queries_f32(const float* __rest
     norm = wave_query_norm(ss);
     scale = norm > 0.f;
   }
+  double out2 = 0.0;
   for (int j = lane; j < dim; j += kWave) {
     const float v = scale ? __fdiv_rn(q[j], norm) : q[j];
-    o[j] = to_bf16 ? round_bf16(v) : v;
+    const float r = to_bf16 ? round_bf16(v) : v;
+    out2 += square_f64(r);
+    o[j] = r;
+  }
+  if (qn2 != nullptr) {
+    out2 = wave_sum_f64(out2);
+    if (lane == 0) qn2[blockIdx.x] = static_cast<float>(out2);
   }
 }
 
 hipError_t launch_prepare_queries(const float* d_q, float* d_qn, int n_queries, int dim, int space, int to_bf16,
                                   hipStream_t stream) {
-  hipLaunchKernelGGL(prepare_queries_f32, dim3(n_queries), dim3(kWave), 0, stream, d_q, d_qn, dim, space, to_bf16, n_queries);
+  hipLaunchKernelGGL(prepare_queries_f32, dim3(n_queries), dim3(kWave), 0, stream, d_q, d_qn, dim, space, to_bf16, n_queries,
+                     static_cast<float*>(nullptr));
   return hipGetLastError();
 }
 
 hipError_t launch_prepare_queries_padded(const float* d_q, float* d_qn, int n_queries, int n_rows_out, int dim, int space,
-                                         hipStream_t stream) {
-  hipLaunchKernelGGL(prepare_queries_f32, dim3(n_rows_out), dim3(kWave), 0, stream, d_q, d_qn, dim, space, 0, n_queries);
+                                         float* d_qn2, hipStream_t stream) {
+  hipLaunchKernelGGL(prepare_queries_f32, dim3(n_rows_out), dim3(kWave), 0, stream, d_q, d_qn, dim, space, 0, n_queries, d_qn2);
   return hipGetLastError();
 }
 

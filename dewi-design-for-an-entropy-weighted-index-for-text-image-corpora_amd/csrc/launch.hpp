@@ -81,8 +81,9 @@ ScanPlan plan_scan(int64_t n_rows, int dim, int elem_bytes, int n_candidates, in
 hipError_t launch_prepare_queries(const float* d_q, float* d_qn, int n_queries, int dim, int space, int to_bf16,
                                   hipStream_t stream);
 // The same (fp32, not rounded) into n_rows_out >= n_queries rows; rows behind the real queries are zero.
+// d_qn2 (may be null): ||prepared query||^2 per output row.
 hipError_t launch_prepare_queries_padded(const float* d_q, float* d_qn, int n_queries, int n_rows_out, int dim, int space,
-                                         hipStream_t stream);
+                                         float* d_qn2, hipStream_t stream);
 // One corpus pass for queries [q0, q0+nq): emits plan.keys_per_query keys per query into
 // d_keys + q * plan.keys_per_query.
 hipError_t launch_scan_f32(const ScanPlan& plan, const float* d_E, int64_t n_rows, int dim, const float* d_q_raw,
@@ -108,7 +109,7 @@ struct MfmaLayout {
 };
 // Normalised (cosine, unless the norm is 0) bf16 queries, [n_rows_out][dim]; rows >= n_queries are zero.
 hipError_t launch_prepare_queries_bf16(const float* d_Q, uint16_t* d_out, int n_queries, int n_rows_out, int dim, int space,
-                                       hipStream_t stream);
+                                       float* d_qn2, hipStream_t stream);
 bool mfma_path_supported(int64_t n_rows, int dim, int n_queries, int n_candidates, int space);
 MfmaLayout plan_mfma(int64_t n_rows, int dim, int n_queries, int n_candidates, int compute_units);
 // Fills cand keys [groups][n_seg][256][seg_cap] and counts [groups][n_seg][256] in the workspace.
@@ -130,7 +131,7 @@ struct MfmaF32Layout {
   int n_blocks;            // workgroups of the filter pass = survivor segments per query
   int n_seg;
   int seg_cap;             // records per (workgroup, query) segment
-  size_t qn_off, thr_off, cnt_off, dense_off, cand_off, total;
+  size_t qn_off, qn2_off, thr_off, cnt_off, dense_off, cand_off, total;   // qn2: ||q||^2 per query (l2 space)
 };
 // elem_type 0: fp32 corpus (>= kMfmaF32MinQueries queries); 1: bf16 corpus (>= kMfmaMinQueries queries: the same
 // depth-split kernel on 32x32x16 bf16 MFMAs — batches of up to 32 queries at the tile-delivery rate, and the

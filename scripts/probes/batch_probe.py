@@ -1,6 +1,6 @@
 """Batched queries on the matrix-core paths: whole-batch time and the event-timed filter pass at 1M x 768 for
 several batch sizes.  Run on the GPU box from the repo root:
-    [DEWI_HIP_LIB=<variant .so>] python3 scripts/probes/batch_probe.py [--bf16] [--k K] [batch sizes...]
+    [DEWI_HIP_LIB=<variant .so>] python3 scripts/probes/batch_probe.py [--bf16] [--l2] [--k K] [--graph] [--pipelined] [batch sizes...]
 (fp32 corpus: csrc/knn_mfma_f32.hip from 5 queries; --bf16: depth pass up to 32 queries, 256-query kernel above.)
 """
 import sys
@@ -21,6 +21,10 @@ if bf16:
 pipelined = "--pipelined" in args      # PipelinedSearcher, two scan streams: consecutive batches overlap their small kernels
 if pipelined:
     args.remove("--pipelined")
+space = "cosine"
+if "--l2" in args:
+    args.remove("--l2")
+    space = "l2"
 k = 10
 if "--k" in args:
     i = args.index("--k")
@@ -29,7 +33,7 @@ if "--k" in args:
 n, d = 1_000_000, 768
 emb = torch.randn((n, d), generator=g, device=dev)
 emb /= emb.norm(dim=1, keepdim=True)
-c = eng.DeviceCorpus(emb, torch.rand(n, device=dev), torch.rand(n, device=dev), "cosine")
+c = eng.DeviceCorpus(emb, torch.rand(n, device=dev), torch.rand(n, device=dev), space)
 if bf16:
     c = c.to_bf16()
     del emb

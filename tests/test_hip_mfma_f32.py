@@ -1,7 +1,7 @@
 """GPU parity tests of the batched fp32 matrix-core path (csrc/knn_mfma_f32.hip) through the C ABI.
 
 The path is taken for >= 5 queries over an fp32 corpus of >= 64 K rows with dim % 256 == 0 (<= 1536),
-cosine space, at most 256 candidates.  Up to dim 1024 every fp32 value is cut into three bf16 pieces
+cosine space (l2: dims to 768, and bf16 corpora of any supported dim), at most 256 candidates.  Up to dim 1024 every fp32 value is cut into three bf16 pieces
 (x = hi + mid + lo exactly) and a block of products is six bf16 matrix instructions with exact products
 and fp32 accumulation; the three dropped cross terms are below 2^-23 of |q_i e_i| each, the size of one
 fp32 rounding (dim 1536 keeps v_mfma_f32_32x32x2_f32 on the fp32 values).  So the oracle comparison is
@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 import dewi_oracle as orc
-from parity import check_batch
+from parity import check_batch, device_prepared_queries
 
 pytestmark = pytest.mark.gpu
 
@@ -129,3 +129,43 @@ def test_mfma_f32_shard_candidates_and_merge_equal_whole():
     ids, sc = eng.merge_rerank_device(torch.stack(lists), 2 * k, k, 0.3, 0.2)
     # per-row sums are the same whichever shard a row is in (same kernel, same depth split), so bit-equal
     assert torch.equal(ids, ids_w) and torch.equal(sc, sc_w)
+
+
+@pytest.mark.parametrize("bf16,dim,n,b,k", [(False, 768, 70_001, 32, 10), (False, 256, 131_073, 12, 10), (False, 512, 80_000, 40, 50),
+                                            (True, 768, 70_001, 32, 10), (True, 1024, 65_600, 9, 10), (True, 256, 100_000, 70, 100)])
+def test_mfma_l2_batched_vs_oracle(bf16, dim, n, b, k):
+    """space="l2" (reference backends.py:434-436: -sum((E - q)^2)) on the depth-split matrix-core pass, which scores
+    2<e,q> - ||e||^2 - ||q||^2 with the row norms summed in the kernel from the fragments it multiplies.  Rows and
+    queries of very different lengths (norms 0.5 .. 2), so the norm terms decide the ranking as much as the products.
+    fp32 corpus: plain oracle comparison (gaps and tolerance scaled by the score magnitude, tests/parity.py); bf16
+    corpus: the oracle on the stored bf16 rows and the device's bf16-rounded queries.  70 queries over a bf16 corpus:
+    the 256-query kernel is cosine-only, so the batch runs as three depth-split passes."""
+    import torch
+    from dewi import _engine as eng
+    rng = np.random.default_rng(dim + b)
+    raw = orc.synth_corpus(n, dim, seed=dim + b) * rng.uniform(0.5, 2.0, size=(n, 1)).astype(np.float32)
+    Q = orc.synth_queries(b, dim, seed=b) * rng.uniform(0.5, 2.0, size=(b, 1)).astype(np.float32)
+    cols = orc.synth_payload_columns(n, seed=dim + b)
+    c = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"], space="l2")
+    dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    kw = dict(exact_gaps=False)
+    if bf16:
+        c = c.to_bf16()
+        E = c.emb.float().cpu().numpy()
+        Qo = device_prepared_queries(Q, "l2")
+        kw = dict(gap=1e-6, score_tol=1e-5, prepared=True)
+    else:
+        E, Qo = c.emb.cpu().numpy(), Q
+        assert np.array_equal(E, raw)                                   # l2 keeps raw rows
+    ids_d, sc_d = c.search_device(torch.from_numpy(Q).cuda(), k, 0.3, 0.1)
+    ids, sc = ids_d.cpu().numpy(), sc_d.cpu().numpy()
+    assert ids.min() >= 0 and not np.isnan(sc).any()
+    check_batch(E, Qo, dewi32, ent32, k, 0.3, 0.1, "l2", ids, sc, min_decisive_frac=0.8 if k <= 10 else 0.25, **kw)
+    # the same rows as the exact row-per-wave l2 kernels (matrix-core paths switched off), up to near-tie swaps
+    eng.tuning(0, 0, -1, 0)
+    try:
+        ids_s, sc_s = c.search(Q[:8], k, 0.3, 0.1)
+    finally:
+        eng.tuning(0, 0, -1, 1)
+    assert np.mean(ids_s == ids[:8]) > 0.97
+    assert np.allclose(np.sort(sc_s, axis=1), np.sort(sc[:8], axis=1), rtol=1e-6, atol=1e-5)    # scores are -||e - q||^2: hundreds
