@@ -51,10 +51,21 @@ for b in sizes:
         c.search_device(Q[i % 8], k, 0.3, 0.0)
     torch.cuda.synchronize()
     t = (time.perf_counter() - t0) / reps
+    bursts = []
+    for nb in (5, 20, 200):              # short bursts from an idle GPU run at a higher clock than a sustained stream
+        torch.cuda.synchronize()
+        time.sleep(0.05)
+        t0 = time.perf_counter()
+        for i in range(nb):
+            c.search_device(Q[i % 8], k, 0.3, 0.0)
+        torch.cuda.synchronize()
+        bursts.append((nb, (time.perf_counter() - t0) / nb * 1e3))
     eng.timing(1)
+    t0 = time.perf_counter()
     for i in range(20):
         c.search_device(Q[i % 8], k, 0.3, 0.0)
     torch.cuda.synchronize()
+    t_timed = (time.perf_counter() - t0) / 20
     ms, cnt = eng.timing_read()
     eng.timing(0)
     ids, _ = c.search_device(Q[0], k, 0.3, 0.0)
@@ -96,4 +107,6 @@ for b in sizes:
             same = bool(torch.equal(oi[0], ids))
             print(f"        pipelined, {streams} scan stream(s): {tp * 1e3:.4f} ms per batch  ids equal {same}", flush=True)
     print(f"B={b:4d} batch {t * 1e3:.4f} ms  filter pass {ms:.4f} ms x {cnt // 20} per batch"
-          f"  ({n * d * elem / ms / 1e6:.0f} GB/s)  refused {int((ids[:, 0] < 0).sum())}", flush=True)
+          f"  ({n * d * elem / ms / 1e6:.0f} GB/s)  refused {int((ids[:, 0] < 0).sum())}"
+          f"  [batch with the events in: {t_timed * 1e3:.4f} ms]  bursts from idle: " + ", ".join(f"{nb}: {ms_:.4f}" for nb, ms_ in bursts),
+          flush=True)
