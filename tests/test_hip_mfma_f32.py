@@ -169,3 +169,39 @@ def test_mfma_l2_batched_vs_oracle(bf16, dim, n, b, k):
         eng.tuning(0, 0, -1, 1)
     assert np.mean(ids_s == ids[:8]) > 0.97
     assert np.allclose(np.sort(sc_s, axis=1), np.sort(sc[:8], axis=1), rtol=1e-6, atol=1e-5)    # scores are -||e - q||^2: hundreds
+
+
+@pytest.mark.parametrize("space,bf16", [("cosine", False), ("l2", False), ("l2", True)])
+def test_mfma_depth_pass_edge_rows(space, bf16):
+    """Edge rows on the depth-split pass, against the exact row-per-wave kernels (matrix-core paths off) of the same
+    library, which the small-size tests pin to the oracle: a NaN row ranks first for every query (NumPy's partition
+    order, reference backends.py:439-444), queries that ARE corpus rows find their row first — under l2 with a score
+    that is zero up to the rounding of 2<e,q> - ||e||^2 - ||q||^2 at the magnitude of ||e||^2 —, an all-zero row and a
+    partial last tile change nothing."""
+    import torch
+    from dewi import _engine as eng
+    n, dim, b, k = 70_003, 512, 16, 10
+    rng = np.random.default_rng(11)
+    raw = orc.synth_corpus(n, dim, seed=11) * rng.uniform(0.5, 2.0, size=(n, 1)).astype(np.float32)
+    raw[40_000] = np.nan if space == "l2" else 0.0        # cosine: a zero row is NaN after the build's normalisation
+    raw[123] = 0.0 if space == "l2" else raw[123]
+    Q = orc.synth_queries(b, dim, seed=12) * np.float32(0.05)
+    Q[:4] = raw[[5, 69_999, 70_002, 31_000]]                # rows of the first, a middle and the (partial) last tile
+    cols = orc.synth_payload_columns(n, seed=11)
+    c = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"], space=space)
+    if bf16:
+        c = c.to_bf16()
+    ids_d, sc_d = c.search_device(torch.from_numpy(Q).cuda(), k, 0.0, 0.0)
+    ids, sc = ids_d.cpu().numpy(), sc_d.cpu().numpy()
+    assert (ids[:, 0] == 40_000).all() and np.isnan(sc[:, 0]).all() and not np.isnan(sc[:, 1:]).any()
+    assert ids[:4, 1].tolist() == [5, 69_999, 70_002, 31_000]
+    if space == "l2":
+        own = np.sum(raw[[5, 69_999, 70_002, 31_000]].astype(np.float64) ** 2, axis=1)
+        assert np.all(np.abs(sc[:4, 1]) <= (4e-3 if bf16 else 2e-6) * own + 1e-6), sc[:4, 1]
+    eng.tuning(0, 0, -1, 0)
+    try:
+        ids_s, sc_s = c.search(Q, k, 0.0, 0.0)
+    finally:
+        eng.tuning(0, 0, -1, 1)
+    assert np.mean(ids_s == ids) > 0.98
+    assert np.allclose(np.sort(sc_s[:, 1:], axis=1), np.sort(sc[:, 1:], axis=1), rtol=2e-6, atol=2e-5 if space == "l2" else 2e-6)
