@@ -78,9 +78,9 @@ def parse_args():
     ap.add_argument("--nontemporal", type=int, default=-1)
     a = ap.parse_args()
     defaults = {"c2": dict(steps=1000, warmup=50, dim=768, k=10, batch=1),
-                # c3: 500 batches = 0.2 s.  A 100-batch run (40 ms) ends before the chip has settled: 0.411 ms per batch
-                # against 0.394 at 400 and at 1000 steps on the same box (same mean kernel time; DVFS, not the code)
-                "c3": dict(steps=500, warmup=20, dim=768, k=100, batch=256),
+                # c3: 100 + 500 batches = 0.24 s.  A 100-batch run (40 ms) ends before the chip has settled: 0.411 ms per
+                # batch against 0.394 at 400 and at 1000 steps on the same box (same mean kernel time; DVFS, not the code)
+                "c3": dict(steps=500, warmup=100, dim=768, k=100, batch=256),
                 "c4": dict(steps=100, warmup=10, dim=768, k=10, batch=1),
                 "c5": dict(steps=50, warmup=5, dim=512, k=10, batch=1)}[a.config]
     for key, val in defaults.items():

@@ -38,14 +38,14 @@ if bf16:
     c = c.to_bf16()
     del emb
 elem = 2 if bf16 else 4
-args = [a for a in args if a != "--graph"]
+args = [a for a in args if a not in ("--graph", "--split")]
 sizes = [int(a) for a in args] or [8, 32, 64, 256]
 for b in sizes:
     Q = torch.randn((8, b, d), generator=g, device=dev)
-    for i in range(5):
+    for i in range(100):                 # ~50 ms of work first: shorter runs are measured while the clocks still settle
         c.search_device(Q[i % 8], k, 0.3, 0.0)
     torch.cuda.synchronize()
-    reps = 60
+    reps = 400
     t0 = time.perf_counter()
     for i in range(reps):
         c.search_device(Q[i % 8], k, 0.3, 0.0)
@@ -69,6 +69,31 @@ for b in sizes:
     ms, cnt = eng.timing_read()
     eng.timing(0)
     ids, _ = c.search_device(Q[0], k, 0.3, 0.0)
+    if "--split" in sys.argv:
+        # the two halves of a batch on their own: dewi_knn_scan (prepare, sample pass, threshold, filter pass) and
+        # dewi_knn_finish (select + re-rank), each as a back-to-back stream
+        from dewi import _native as nat
+        lib = nat.load_library()
+        cc = min(2 * k, n)
+        need = int(lib.dewi_knn_workspace_bytes(n, d, b, cc))
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        oi = torch.empty((b, k), dtype=torch.int64, device=dev)
+        osc = torch.empty((b, k), dtype=torch.float32, device=dev)
+        et, sp = (1 if bf16 else 0), nat.SPACE_CODES[space]
+        def scan(i):
+            nat.check(lib.dewi_knn_scan(nat.ptr(c.emb), et, n, d, nat.ptr(Q[i % 8]), b, cc, sp, nat.ptr(ws), need, nat.stream_ptr()))
+        def fin():
+            nat.check(lib.dewi_knn_finish(nat.ptr(ws), need, et, n, d, b, cc, sp, k, 0.3, 0.0, nat.ptr(c.dewi32), nat.ptr(c.ent32), 0,
+                                          nat.ptr(oi), nat.ptr(osc), 0, nat.stream_ptr()))
+        for what, fn in (("scan", scan), ("finish", lambda i: fin()), ("scan+finish", lambda i: (scan(i), fin()))):
+            for i in range(5):
+                fn(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(reps):
+                fn(i)
+            torch.cuda.synchronize()
+            print(f"        {what}: {(time.perf_counter() - t0) / reps * 1e3:.4f} ms", flush=True)
     if "--graph" in sys.argv:
         # the batch's five kernels replayed from a captured graph: what the dependent-launch gaps cost
         oi = torch.empty((b, k), dtype=torch.int64, device=dev)
