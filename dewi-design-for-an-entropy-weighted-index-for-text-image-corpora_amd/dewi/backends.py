@@ -274,11 +274,12 @@ class ExactIndex(BaseIndex):
         from . import _native as nat
         cols = self._payload_columns()
         dev = self._corpus.device
-        d = [torch.from_numpy(cols[k]).to(dev) for k in ("dewi", "ht_mean", "hi_mean")]
-        nat.check(nat.load_library().dewi_payload_soa_f64(nat.ptr(d[0]), nat.ptr(d[1]), nat.ptr(d[2]),
-                                                          nat.ptr(self._corpus.dewi32), nat.ptr(self._corpus.ent32),
-                                                          len(self._doc_ids), nat.stream_ptr()))
-        torch.cuda.current_stream().synchronize()
+        with torch.cuda.device(dev):                       # the kernel goes on THAT device's current stream
+            d = [torch.from_numpy(cols[k]).to(dev) for k in ("dewi", "ht_mean", "hi_mean")]
+            nat.check(nat.load_library().dewi_payload_soa_f64(nat.ptr(d[0]), nat.ptr(d[1]), nat.ptr(d[2]),
+                                                              nat.ptr(self._corpus.dewi32), nat.ptr(self._corpus.ent32),
+                                                              len(self._doc_ids), nat.stream_ptr()))
+            torch.cuda.current_stream().synchronize()
 
     # ---------------------------------------------------------------- stored rows on the host
     def _stored_rows(self) -> np.ndarray:
