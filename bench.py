@@ -71,7 +71,8 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=None, help="queries per step")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--emulate-shards", type=int, default=8, help="--config c4: resident shards on the one GPU")
-    ap.add_argument("--cpu-queries", type=int, default=64, help="queries timed on the CPU oracle (0 = skip; at least 50 are run)")
+    ap.add_argument("--cpu-queries", type=int, default=512,
+                    help="queries timed on the CPU oracle: ~10 s of CPU work at C2, cut off after 30 s (0 = skip; at least 50 are run)")
     ap.add_argument("--latency-queries", type=int, default=200)
     ap.add_argument("--condition-ms", type=float, default=200.0,
                     help="untimed scanning before the warm-up steps, so that the timed region starts on settled clocks")
