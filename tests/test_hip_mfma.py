@@ -84,6 +84,27 @@ def test_mfma_overflow_falls_back_to_exact_path():
     assert np.allclose(sc[5], 1.0, atol=1e-2)
 
 
+@pytest.mark.parametrize("space", ["cosine", "l2"])
+def test_pipelined_batches_in_both_spaces(space):
+    """dewi_knn_finish plans from the space it is given (ABI 3): an l2 batch of 12 over an fp32 corpus is a depth-split
+    pass, over a 40 000-row corpus the row kernels — scan and finish must agree on that in either space."""
+    from dewi import _engine as eng
+    import torch
+    for n in (100_000, 40_000):
+        dim, b, k = 256, 12, 10
+        raw = orc.synth_corpus(n, dim, seed=5) * np.float32(1.5)
+        cols = orc.synth_payload_columns(n, seed=5)
+        c = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"], space=space)
+        q_dev = torch.from_numpy(orc.synth_queries(b, dim, seed=6) * np.float32(0.1)).cuda()
+        want_ids, want_sc = c.search_device(q_dev, k, 0.3, 0.1)
+        pipe = eng.PipelinedSearcher(c, k, 0.3, 0.1, n_queries=b)
+        ids = torch.empty((b, k), dtype=torch.int64, device="cuda")
+        sc = torch.empty((b, k), dtype=torch.float32, device="cuda")
+        pipe.submit(q_dev, ids, sc)
+        pipe.drain()
+        assert torch.equal(ids, want_ids) and torch.equal(sc, want_sc)
+
+
 @pytest.mark.parametrize("bf16,b", [(True, 40), (True, 8), (False, 12)])
 def test_pipelined_batches_take_the_matrix_core_paths_and_equal_the_one_call_search(bf16, b):
     """dewi_knn_scan + dewi_knn_finish (two streams, rotating workspaces) choose the same path as the one-call
