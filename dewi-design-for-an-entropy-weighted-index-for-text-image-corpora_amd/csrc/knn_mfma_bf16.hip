@@ -948,29 +948,95 @@ __global__ __launch_bounds__(kSelectThreads) void sample_threshold_kernel(const 
   const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
   const f32x4s* s4 = reinterpret_cast<const f32x4s*>(dense + static_cast<int64_t>(blockIdx.x) * stride);
   const int n4 = static_cast<int>(n_sample >> 2);
-  // Two radix passes (the top 22 bits of the key): the threshold is the LOWER EDGE of the 22-bit bin that holds the
-  // c-th largest group maximum — still a valid lower bound of the c-th best score, looser by less than 2^-13 of its
-  // value (a few more survivors in a few thousand); the third pass that made it exact cost 2.5 us per batch.
-  RadixPick st{0u, static_cast<uint32_t>(n_candidates), false};
-  for (int pass = 0; pass < 2; ++pass) {
-    const int bits = 11;
-    const int shift = pass == 0 ? 21 : 10;
-    for (int b = tid; b < kBins; b += nt) hist[b] = 0;
-    __syncthreads();
-#pragma unroll 2
-    for (int i = tid; i < n4; i += nt) {
-      u32x4s key;
-      if (STAGED && pass > 0) {
-        key = reinterpret_cast<const u32x4s*>(staged)[i];
-      } else {
-        const f32x4s v = s4[i];
+  // Two radix passes of up to 11 bits over the keys' offsets from the SMALLEST key of the query (block minimum and
+  // maximum first): real scores crowd into a narrow range — cosines of one corpus, or l2 scores around -||q||^2 — and
+  // the top bits of the raw key are then the same for all 8192 values: every LDS atomic of a pass hit one bin and
+  // serialised (13 us instead of 7 on l2 batches).  The threshold is the LOWER EDGE of the bin the second pass ends in:
+  // exact when the span is below 2^22, else a valid lower bound of the c-th best score, looser by less than 2^-11 of
+  // the span (a few more survivors in a few thousand); a third pass that made it exact cost 2.5 us per batch.
+  __shared__ uint32_t wave_min[kSelectThreads / kWave], wave_max[kSelectThreads / kWave];
+  // up to 8 keys per thread (8192 group maxima: every launch of this library) stay in registers for both passes;
+  // longer inputs go through the staged LDS copy / are read again
+  constexpr int kRegIter = 2;
+  const bool in_regs = n4 <= kRegIter * nt;
+  u32x4s kreg[kRegIter];
+  uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+  if (in_regs) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) key[e] = ord_f32(v[e]);
-        if (STAGED) reinterpret_cast<u32x4s*>(staged)[i] = key;
-      }
+    for (int u = 0; u < kRegIter; ++u) {
+      const int i = tid + u * nt;
+      f32x4s v = {0.f, 0.f, 0.f, 0.f};
+      if (i < n4) v = s4[i];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if (pass == 0 || (key[e] >> (shift + bits)) == st.prefix) atomicAdd(&hist[(key[e] >> shift) & ((1u << bits) - 1u)], 1u);
+        kreg[u][e] = ord_f32(v[e]);
+        if (i < n4) {
+          kmin = kreg[u][e] < kmin ? kreg[u][e] : kmin;
+          kmax = kreg[u][e] > kmax ? kreg[u][e] : kmax;
+        }
+      }
+    }
+  } else {
+    for (int i = tid; i < n4; i += nt) {
+      const f32x4s v = s4[i];
+      u32x4s key;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        key[e] = ord_f32(v[e]);
+        kmin = key[e] < kmin ? key[e] : kmin;
+        kmax = key[e] > kmax ? key[e] : kmax;
+      }
+      if (STAGED) reinterpret_cast<u32x4s*>(staged)[i] = key;
+    }
+  }
+  kmin = wave_min_u32(kmin);
+  kmax = wave_max_u32(kmax);
+  if ((tid & 63) == 0) {
+    wave_min[tid >> 6] = kmin;
+    wave_max[tid >> 6] = kmax;
+  }
+  for (int b = tid; b < kBins; b += nt) hist[b] = 0;
+  __syncthreads();
+  for (int w = 0; w < nt / kWave; ++w) {
+    kmin = wave_min[w] < kmin ? wave_min[w] : kmin;
+    kmax = wave_max[w] > kmax ? wave_max[w] : kmax;
+  }
+  const uint32_t base = kmin, span = kmax - kmin;
+  const int total_bits = span ? 32 - __builtin_clz(span) : 1;
+  const int shift1 = total_bits > 11 ? total_bits - 11 : 0;
+  const int shift2 = shift1 > 11 ? shift1 - 11 : 0;
+  RadixPick st{0u, static_cast<uint32_t>(n_candidates), false};
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1 && shift1 == 0) break;            // the first pass resolved every bit of the span
+    const int bits = pass == 0 ? 11 : shift1 - shift2;
+    const int shift = pass == 0 ? shift1 : shift2;
+    if (pass > 0) {                                 // (the first pass's histogram was cleared before the barrier above)
+      for (int b = tid; b < kBins; b += nt) hist[b] = 0;
+      __syncthreads();
+    }
+    auto count = [&](const u32x4s& key) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t off = key[e] - base;
+        if (pass == 0 || (off >> shift1) == st.prefix) atomicAdd(&hist[(off >> shift) & ((1u << bits) - 1u)], 1u);
+      }
+    };
+    if (in_regs) {
+#pragma unroll
+      for (int u = 0; u < kRegIter; ++u)
+        if (tid + u * nt < n4) count(kreg[u]);
+    } else {
+#pragma unroll 2
+      for (int i = tid; i < n4; i += nt) {
+        u32x4s key;
+        if (STAGED) {
+          key = reinterpret_cast<const u32x4s*>(staged)[i];
+        } else {
+          const f32x4s v = s4[i];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) key[e] = ord_f32(v[e]);
+        }
+        count(key);
       }
     }
     __syncthreads();
@@ -980,7 +1046,7 @@ __global__ __launch_bounds__(kSelectThreads) void sample_threshold_kernel(const 
       return;
     }
   }
-  if (tid == 0) thr[blockIdx.x] = unord_f32(st.prefix << 10);
+  if (tid == 0) thr[blockIdx.x] = unord_f32(base + (st.prefix << (shift1 == 0 ? 0 : shift2)));
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -4,7 +4,8 @@
 # 1. rocprofv3 --kernel-trace --stats of the default bench command (c2), of --config c3 and --config c5
 # 2. PMC passes, ONE COUNTER SET PER RUN and never together with a trace domain: FETCH_SIZE, WRITE_SIZE (c2, c3),
 #    then the SQ counters of the matrix-core kernel (c3): LDS bank conflicts, MFMA / VALU busy, wait cycles
-#    and of the fp32 depth-split pass (32 queries, scripts/probes/batch_probe.py): FETCH_SIZE, MFMA / VALU busy, LDS
+#    and of the depth-split pass (32 queries, scripts/probes/batch_probe.py; fp32 cosine, bf16, fp32 l2): FETCH_SIZE,
+#    MFMA / VALU busy, LDS
 # 3. scripts/summarize_pmc.py -> pmc_summary.{txt,json} and hbm_traffic.json (bench.py's roofline.traffic)
 # The program itself (python3 bench.py) follows `--` directly: no env/bash hop under the profiler.
 set -e
@@ -53,6 +54,10 @@ pmc SQ_LDS_c3 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYC
 pmc SQ_MFMA_c3 "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_COEXEC_CYCLES" --config c3 --steps 10 --warmup 2
 pmc SQ_WAIT_c3 "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" --config c3 --steps 10 --warmup 2
 probe_trace f32b32 32
+probe_trace bf16b32 --bf16 32
+probe_trace f32l2b32 --l2 32
+probe_pmc FETCH_SIZE_bf16b32 FETCH_SIZE --bf16 32
+probe_pmc FETCH_SIZE_f32l2b32 FETCH_SIZE --l2 32
 probe_pmc FETCH_SIZE_f32b32 FETCH_SIZE 32
 probe_pmc SQ_MFMA_f32b32 "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" 32
 probe_pmc SQ_LDS_f32b32 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" 32
