@@ -205,3 +205,50 @@ def test_mfma_depth_pass_edge_rows(space, bf16):
         eng.tuning(0, 0, -1, 1)
     assert np.mean(ids_s == ids) > 0.98
     assert np.allclose(np.sort(sc_s[:, 1:], axis=1), np.sort(sc[:, 1:], axis=1), rtol=2e-6, atol=2e-5 if space == "l2" else 2e-6)
+
+
+def _random_depth_cases(n_cases=14, seed=2024):
+    rs = np.random.RandomState(seed)
+    cases = []
+    for i in range(n_cases):
+        bf16 = bool(rs.randint(2))
+        space = "l2" if rs.rand() < 0.4 else "cosine"
+        dims = [256, 512, 768, 1024, 1536] if (bf16 or space == "cosine") else [256, 512, 768]
+        dim = int(rs.choice(dims))
+        n = int(rs.randint(65_536, 110_000))
+        b = int(rs.randint(5 if not bf16 else 2, 71))
+        if bf16 and space == "cosine" and dim <= 768 and b > 32:
+            b = int(rs.randint(2, 33))                     # larger bf16 cosine batches belong to the 256-query kernel's tests
+        k = int(rs.choice([1, 5, 10, 50, 128]))
+        cases.append((i, bf16, space, dim, n, b, k, float(rs.choice([0.0, 0.3, 0.7])), float(rs.choice([0.0, 0.2]))))
+    return cases
+
+
+@pytest.mark.parametrize("case", _random_depth_cases(), ids=lambda c: f"{c[0]}-{'bf16' if c[1] else 'f32'}-{c[2]}-d{c[3]}-n{c[4]}-b{c[5]}-k{c[6]}")
+def test_depth_pass_randomised_cases(case):
+    """Seeded random shapes on the depth-split pass — ragged last tiles (n % 32), partial query groups (b % 32), one to
+    three passes, k from 1 to 128 (2k candidates up to 256), both spaces, both element types, every chunk count — each
+    against the oracle (bf16: on the stored rows and the device's prepared queries)."""
+    import torch
+    from dewi import _engine as eng
+    i, bf16, space, dim, n, b, k, eta, pref = case
+    rng = np.random.default_rng(1000 + i)
+    raw = orc.synth_corpus(n, dim, seed=300 + i)
+    Q = orc.synth_queries(b, dim, seed=400 + i)
+    if space == "l2":
+        raw = raw * rng.uniform(0.5, 2.0, size=(n, 1)).astype(np.float32)
+        Q = Q * np.float32(0.05) * rng.uniform(0.5, 2.0, size=(b, 1)).astype(np.float32)
+    cols = orc.synth_payload_columns(n, seed=300 + i)
+    c = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"], space=space)
+    dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    kw = dict(exact_gaps=False)
+    if bf16:
+        c = c.to_bf16()
+        E, Qo = c.emb.float().cpu().numpy(), device_prepared_queries(Q, space)
+        kw = dict(gap=1e-6, score_tol=1e-5, prepared=True)
+    else:
+        E, Qo = c.emb.cpu().numpy(), Q
+    ids_d, sc_d = c.search_device(torch.from_numpy(Q).cuda(), k, eta, pref)
+    ids, sc = ids_d.cpu().numpy(), sc_d.cpu().numpy()
+    assert ids.min() >= 0 and not np.isnan(sc).any()
+    check_batch(E, Qo, dewi32, ent32, k, eta, pref, space, ids, sc, min_decisive_frac=0.6 if k <= 10 else 0.25, **kw)
