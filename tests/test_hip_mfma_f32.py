@@ -111,20 +111,21 @@ def test_mfma_f32_overflow_falls_back_to_exact_path():
     assert np.allclose(sc[5], 1.0, atol=1e-5)
 
 
-def test_mfma_f32_shard_candidates_and_merge_equal_whole():
+@pytest.mark.parametrize("space", ["cosine", "l2"])
+def test_mfma_f32_shard_candidates_and_merge_equal_whole(space):
     """Two fp32 shards answered by the matrix-core path (dewi_knn_candidates) + merge == the whole corpus."""
     import torch
     from dewi import _engine as eng
     n, d, k = 140_000, 256, 10
-    raw = orc.synth_corpus(n, d, seed=21)
+    raw = orc.synth_corpus(n, d, seed=21) * np.float32(1.0 if space == "cosine" else 1.7)
     cols = orc.synth_payload_columns(n, seed=21)
-    Q = torch.from_numpy(orc.synth_queries(20, d, seed=22)).cuda()
-    whole = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    Q = torch.from_numpy(orc.synth_queries(20, d, seed=22) * np.float32(1.0 if space == "cosine" else 0.1)).cuda()
+    whole = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"], space=space)
     ids_w, sc_w = whole.search_device(Q, k, 0.3, 0.2)
     lists = []
     for lo, hi in ((0, 70_000), (70_000, n)):
         sub = {key: v[lo:hi] for key, v in cols.items()}
-        sh = eng.DeviceCorpus.from_host(raw[lo:hi], sub["dewi"], sub["ht_mean"], sub["hi_mean"], id_offset=lo)
+        sh = eng.DeviceCorpus.from_host(raw[lo:hi], sub["dewi"], sub["ht_mean"], sub["hi_mean"], id_offset=lo, space=space)
         lists.append(sh.candidates_device(Q, 2 * k))
     ids, sc = eng.merge_rerank_device(torch.stack(lists), 2 * k, k, 0.3, 0.2)
     # per-row sums are the same whichever shard a row is in (same kernel, same depth split), so bit-equal
