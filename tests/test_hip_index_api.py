@@ -197,6 +197,34 @@ def test_batch_api_equals_single_queries():
     assert len(index) == N_DOCS + 1
 
 
+@pytest.mark.parametrize("space", ["cosine", "l2"])
+def test_batch_api_on_the_matrix_core_pass_equals_single_queries(space):
+    """DewiIndex.search_batch at a size where a batch takes the depth-split matrix-core pass (>= 64 K rows, >= 5
+    queries; cosine and l2) against DewiIndex.search one query at a time (row-per-wave kernels): same documents up to
+    near-tie swaps, scores equal to fp32 rounding, the same Payload objects."""
+    from dewi.index import DewiIndex
+    n, dim, b, k = 70_000, 256, 12, 10
+    rs = np.random.RandomState(3)
+    embs = rs.randn(n, dim).astype(np.float32)
+    cols = {"dewi": np.clip(rs.beta(2, 2, n), 0, 1), "ht_mean": rs.gamma(2, 0.5, n), "ht_q90": rs.gamma(2, 0.5, n) * 1.5,
+            "hi_mean": rs.gamma(2, 0.3, n), "hi_q90": rs.gamma(2, 0.3, n) * 1.5, "I_hat": rs.beta(2, 2, n),
+            "redundancy": rs.beta(1, 5, n), "noise": rs.beta(1, 10, n)}
+    index = DewiIndex(dim=dim, space=space, use_ann=False)
+    index.add_batch_columns([f"doc_{i}" for i in range(n)], embs, cols)
+    qs = rs.randn(b, dim).astype(np.float32)
+    batched = index.search_batch(qs, k=k, eta=0.3)
+    agree = 0
+    for q, res in zip(qs, batched):
+        single = index.search(q, k=k, eta=0.3)
+        agree += sum(a[0] == r[0] for a, r in zip(single, res))
+        scale = max(1.0, max(abs(r[1]) for r in res))
+        assert np.allclose(sorted(a[1] for a in single), sorted(r[1] for r in res), rtol=0, atol=3e-6 * scale)
+        for a, r in zip(single, res):
+            if a[0] == r[0]:
+                assert a[2] is r[2]
+    assert agree >= 0.97 * b * k
+
+
 @pytest.mark.parametrize("flag", [None, "--objects", "--per-row-add"])
 def test_profile_harness_writes_the_reference_metrics_layout(tmp_path, flag):
     """scripts/profile_index.py — the reference harness's command line (reference scripts/profile_index.py:239-292)
