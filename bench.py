@@ -286,6 +286,20 @@ def run_c2(args, torch, dist, eng, nat, rank, world, device):
         send = [torch.empty((G, B, c, 4), dtype=torch.int32, device=device) for _ in range(nbuf)]
         recv = [torch.empty((world * G * B * c * 4,), dtype=torch.int32, device=device) for _ in range(nbuf)]
         from collections import deque
+        rehearsal = dist.get_backend() != "nccl"     # DEWI_BENCH_BACKEND=gloo: the loop's logic on ranks that share a GPU
+
+        class _Done:
+            def wait(self):
+                return True
+
+        def gather_records(dst, src):
+            if not rehearsal:
+                return dist.all_gather_into_tensor(dst, src, async_op=True)
+            h_src = src.cpu()                          # synchronises the finish stream; staged through the host
+            h_dst = torch.empty(dst.numel(), dtype=dst.dtype)
+            dist.all_gather_into_tensor(h_dst, h_src)
+            dst.copy_(h_dst)
+            return _Done()
 
         def finish_group(work, j0, g, s):
             work.wait()
@@ -301,7 +315,7 @@ def run_c2(args, torch, dist, eng, nat, rank, world, device):
                 s = n_group % nbuf
                 for u in range(g):
                     pipe.submit(qs[j0 + u], out_records=send[s][u])
-                work = dist.all_gather_into_tensor(recv[s][: world * g * B * c * 4], send[s][:g].view(-1), async_op=True)
+                work = gather_records(recv[s][: world * g * B * c * 4], send[s][:g].view(-1))
                 inflight.append((work, j0, g, s))
                 if len(inflight) >= depth:
                     finish_group(*inflight.popleft())
@@ -342,7 +356,7 @@ def run_c2(args, torch, dist, eng, nat, rank, world, device):
     region_ms, region_launches = eng.timing_read()
     eng.timing(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # Roofline leg: the same loop body, every scan bracketed, at least MIN_ROOFLINE_LAUNCHES launches whatever
@@ -381,7 +395,9 @@ def run_c2(args, torch, dist, eng, nat, rank, world, device):
         "config": {"workload": f"{total_rows} docs x d={args.dim} fp32, query batch={B}, k={k}, eta={eta}, "
                                f"brute-force cosine kNN + DEWI re-rank (BASELINE.json configs[1])",
                    "docs": total_rows, "dim": args.dim, "k": k, "eta": eta, "batch": B, "candidates": c,
-                   "parallelism": f"doc-id shards x{world} + RCCL all-gather" if sharded else "single GPU",
+                   "parallelism": (f"doc-id shards x{world} + RCCL all-gather" if not sharded or dist.get_backend() == "nccl" else
+                                   f"REHEARSAL: {world} ranks on shared GPUs, records staged through the host ({dist.get_backend()})")
+                   if sharded else "single GPU",
                    "queries_in_flight": 1 if (serial and not sharded) else (3 * G if sharded else 2),
                    "rows_per_gpu": n_local, "conditioning_steps_before_warmup": n_condition},
         "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
@@ -433,7 +449,7 @@ def run_c2(args, torch, dist, eng, nat, rank, world, device):
         for j in range(n_lat):
             t1 = time.perf_counter()
             pipe.submit(qs[j], out_records=send[0][0])
-            dist.all_gather_into_tensor(recv[0][: world * B * c * 4], send[0][:1].view(-1))
+            gather_records(recv[0][: world * B * c * 4], send[0][:1].view(-1)).wait()
             eng.merge_rerank_device(recv[0][: world * B * c * 4].view(world, B, c, 4), c, k, eta, 0.0, oi[j], osc[j])
             torch.cuda.synchronize()
             lat.append(time.perf_counter() - t1)
@@ -901,12 +917,20 @@ def main():
         args.gpus = world
     if world > 1 and args.config != "c2":
         raise SystemExit("--config c3/c4/c5 are single-GPU harness legs; the multi-GPU run is the default config")
+    # DEWI_BENCH_BACKEND=gloo DEWI_BENCH_DEVICE=0: REHEARSAL of the multi-rank loop (slicing, grouping, merge, parity
+    # and latency legs) with several ranks sharing one GPU and records staged through the host — its numbers mean nothing
+    backend = os.environ.get("DEWI_BENCH_BACKEND", "nccl")
+    if "DEWI_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["DEWI_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     device = torch.device(f"cuda:{local_rank}")
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         with stdout_to_stderr():
-            dist.init_process_group(backend="nccl", device_id=device)
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=device)
+            else:
+                dist.init_process_group(backend=backend)
             dist.barrier()                                   # brings the communicator (and RCCL's banner) up here
 
     from dewi import _engine as eng
