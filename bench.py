@@ -376,7 +376,8 @@ def run_c2(args, torch, dist, eng, nat, rank, world, device):
     elem = corpus.emb.element_size()
     algo_bytes = n_local * args.dim * elem + B * args.dim * 4           # per scan launch, this rank
     achieved = algo_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-    kernel = "scan_rows_f32"
+    # --batch >= 5 over the fp32 corpus: the depth-split matrix-core pass is the dominant kernel (one per 32 queries)
+    kernel = "scan_rows_f32" if B < 5 else f"mfma_scan_f32<false,{args.dim // 256},false,false>"
     traffic, traffic_note = recorded_traffic(f"{n_local}x{args.dim}x{elem}xB{B}", kernel)
 
     result = {
