@@ -416,6 +416,18 @@ def run_c2(args, torch, dist, eng, nat, rank, world, device):
         # rate says what the GPU actually streamed.
         result["roofline"]["scans_in_flight"] = int(os.environ.get("DEWI_BENCH_SCAN_STREAMS", "2"))
         result["roofline"]["effective_GBps_per_gpu"] = round(algo_bytes * args.steps / elapsed / 1e9, 1)
+        # what the process group actually was: every rank contributes (rank, device ordinal, rows held) through the
+        # same backend the exchange used, so the record shows that the collective library saw N ranks
+        on_dev = dist.get_backend() == "nccl"
+        mine = torch.tensor([rank, device.index, n_local], dtype=torch.int64, device=device if on_dev else "cpu")
+        seen = torch.empty((dist.get_world_size(), 3), dtype=torch.int64, device=mine.device)
+        dist.all_gather_into_tensor(seen.view(-1), mine)
+        seen = seen.cpu().tolist()
+        result["rccl"] = {"backend": dist.get_backend(), "world": dist.get_world_size(),
+                          "ranks_seen": [r[0] for r in seen], "devices": [r[1] for r in seen],
+                          "rows_per_rank": [r[2] for r in seen],
+                          "exchange": {"collective": "all_gather_into_tensor", "bytes_per_rank_per_query": B * c * 16,
+                                       "queries_per_collective": G}}
 
     # ------------------------------------------------------------------ sharded result == single-GPU result
     if rank == 0 and sharded:
@@ -455,6 +467,16 @@ def run_c2(args, torch, dist, eng, nat, rank, world, device):
             torch.cuda.synchronize()
             lat.append(time.perf_counter() - t1)
         pipe.drain()
+        # the exchange alone: one all-gather of one query's records, waited for on the host, nothing else in flight
+        barrier()
+        xch = []
+        for j in range(min(n_lat, 100)):
+            t1 = time.perf_counter()
+            gather_records(recv[0][: world * B * c * 4], send[0][:1].view(-1)).wait()
+            torch.cuda.synchronize()
+            xch.append(time.perf_counter() - t1)
+        if rank == 0 and len(xch) > 5:
+            result["rccl"]["exchange"]["alone_p50_ms"] = round(float(np.percentile(np.array(xch[5:]) * 1e3, 50)), 4)
         lat = np.array(lat[5:]) * 1e3
         if rank == 0 and len(lat):
             result["p50_latency_ms"] = round(float(np.percentile(lat, 50)), 4)
@@ -904,8 +926,36 @@ def run_c5(args, torch, nat, device):
     return result
 
 
+def free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n_ranks: int) -> int:
+    """`python bench.py --gpus N` started by hand (no WORLD_SIZE in the environment): start the N ranks as a CHILD
+    `python -m torch.distributed.run` of this very command line and hand its exit code back.  Nothing in this process
+    has touched the GPU (torch is not even imported yet), and nothing is exec'ed: the child inherits stdout, so rank 0's
+    JSON line reaches whoever reads ours.  DEWI_BENCH_LAUNCH_DRYRUN=1 prints the command instead of running it."""
+    import subprocess
+    port = int(os.environ.get("MASTER_PORT", "0")) or free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    if os.environ.get("DEWI_BENCH_LAUNCH_DRYRUN", "0") == "1":
+        print(json.dumps({"launcher": cmd}))
+        return 0
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.pop("MASTER_PORT", None)
+    print(f"bench.py: --gpus {n_ranks} without a launcher: starting {n_ranks} ranks with torch.distributed.run "
+          f"(127.0.0.1:{port})", file=sys.stderr)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
     import torch
     import torch.distributed as dist
 
@@ -913,8 +963,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s): running at {world}", file=sys.stderr)
         args.gpus = world
     if world > 1 and args.config != "c2":
         raise SystemExit("--config c3/c4/c5 are single-GPU harness legs; the multi-GPU run is the default config")

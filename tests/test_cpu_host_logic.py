@@ -231,3 +231,23 @@ def test_blocking_search_is_serialised_per_corpus():
         torch.cuda.device, torch.empty, torch.cuda.current_stream = real_device, real_empty, real_sync
     assert ids.shape == (1, 2) and held and all(held), held
     assert not owned()                                   # released afterwards
+
+
+def test_bench_plain_gpus_n_reaches_the_launcher():
+    """`python bench.py --gpus 4` with no launcher around it must start its own ranks (child torch.distributed.run, nothing
+    exec'ed, no GPU touched first) instead of exiting: DEWI_BENCH_LAUNCH_DRYRUN prints the command it would run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["DEWI_BENCH_LAUNCH_DRYRUN"] = "1"
+    r = subprocess.run([sys.executable, str(repo / "bench.py"), "--gpus", "4", "--steps", "7", "--warmup", "3"],
+                       capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    cmd = json.loads(r.stdout.strip().splitlines()[-1])["launcher"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    tail = cmd[cmd.index(str(repo / "bench.py")) + 1:]
+    assert tail == ["--gpus", "4", "--steps", "7", "--warmup", "3"]          # the same command line reaches every rank
