@@ -256,12 +256,22 @@ int batch_scan(const BatchPlan& P, const void* d_E, int elem_type, int64_t n_row
 
 // k > 0: ids / scores of the re-ranked top k.  k == 0: n_candidates records per query into d_out_cand (an overflowed
 // query of a matrix-core path carries id -2 there, -1 in the id output).
-int batch_select(const BatchPlan& P, const void* d_ws, size_t ws_bytes, int n_queries, int n_candidates, int k,
+int batch_select(const BatchPlan& P, void* d_ws, size_t ws_bytes, int n_queries, int n_candidates, int k,
                  const dewi::RerankParams& rp, const float* d_dewi32, const float* d_ent32, int64_t id_offset,
                  int64_t* d_out_ids, float* d_out_scores, dewi_candidate* d_out_cand, hipStream_t stream) {
   if (!d_ws || ws_bytes < P.total) return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, P.total);
-  const char* ws = static_cast<const char*>(d_ws);
+  char* ws = static_cast<char*>(d_ws);
   hipError_t e = hipSuccess;
+  if (P.path == BatchPath::Rows && P.c_local > dewi::kMaxSortCandidates) {
+    // k > 1024 (dense keys from the row kernels): the candidate arrays live in the workspace, not in LDS
+    const KnnLayout& L = P.rows;
+    uint64_t* g1 = reinterpret_cast<uint64_t*>(ws + L.big_off);
+    e = dewi::launch_select_rerank_large(reinterpret_cast<const uint64_t*>(ws + L.keys_off), L.plan.keys_per_query, n_queries,
+                                         P.c_local, L.p2, k, rp, d_dewi32, d_ent32, id_offset, g1,
+                                         g1 + static_cast<size_t>(n_queries) * L.p2, d_out_ids, d_out_scores, d_out_cand,
+                                         n_candidates, stream);
+    return e == hipSuccess ? DEWI_OK : hip_fail(e, "select_rerank_large launch");
+  }
   if (P.path == BatchPath::Rows) {
     const KnnLayout& L = P.rows;
     const int sorted = (L.plan.slots == 1 && P.c_local == n_candidates) ? L.plan.n_lists : 0;
@@ -320,17 +330,6 @@ int knn_rerank_impl(const void* d_E, int elem_type, int64_t n_rows, int dim, con
   rc = batch_scan(P, d_E, elem_type, n_rows, dim, d_Q, n_queries, c, space, d_ws, ws_bytes, dev.cus, stream);
   if (rc) return rc;
   const dewi::RerankParams rp = make_rerank(eta, pref, transform, space);
-  if (c > dewi::kMaxSortCandidates) {  // k > 1024 (row kernels only): candidate arrays live in global memory
-    const KnnLayout& L = P.rows;
-    char* ws = static_cast<char*>(d_ws);
-    uint64_t* g1 = reinterpret_cast<uint64_t*>(ws + L.big_off);
-    hipError_t e2 = dewi::launch_select_rerank_large(reinterpret_cast<const uint64_t*>(ws + L.keys_off),
-                                                     L.plan.keys_per_query, n_queries, c, L.p2, k, rp, d_dewi32, d_ent32, g1,
-                                                     g1 + static_cast<size_t>(n_queries) * L.p2, d_out_ids, d_out_scores,
-                                                     stream);
-    if (e2 != hipSuccess) return hip_fail(e2, "select_rerank_large launch");
-    return DEWI_OK;
-  }
   return batch_select(P, d_ws, ws_bytes, n_queries, c, k, rp, d_dewi32, d_ent32, 0, d_out_ids, d_out_scores, nullptr, stream);
 }
 
@@ -437,8 +436,7 @@ int dewi_knn_scan(const void* d_E, int elem_type, int64_t n_rows, int dim, const
   int rc = check_common(d_E, n_rows, dim, d_Q, n_queries, space);
   if (rc) return rc;
   if (n_candidates <= 0) return DEWI_OK;
-  if (n_candidates > dewi::kMaxSortCandidates)
-    return fail(DEWI_ERR_UNSUPPORTED, "n_candidates %d exceeds %d", n_candidates, dewi::kMaxSortCandidates);
+  if (n_candidates > (1 << 30)) return fail(DEWI_ERR_UNSUPPORTED, "n_candidates %d exceeds 2^30", n_candidates);
   DeviceInfo dev;
   rc = ensure_device(dev);
   if (rc) return rc;
@@ -447,15 +445,14 @@ int dewi_knn_scan(const void* d_E, int elem_type, int64_t n_rows, int dim, const
                     static_cast<hipStream_t>(stream_));
 }
 
-int dewi_knn_finish(const void* d_workspace, size_t workspace_bytes, int elem_type, int64_t n_rows, int dim,
+int dewi_knn_finish(void* d_workspace, size_t workspace_bytes, int elem_type, int64_t n_rows, int dim,
                     int n_queries, int n_candidates, int space, int k, double eta, double entropy_pref,
                     const float* d_dewi32, const float* d_ent32, int64_t id_offset, int64_t* d_out_ids,
                     float* d_out_scores, dewi_candidate* d_out_cand, void* stream_) {
   if (n_rows <= 0 || dim <= 0 || n_queries <= 0) return fail(DEWI_ERR_INVALID_ARG, "non-positive size");
   if (space != DEWI_SPACE_COSINE && space != DEWI_SPACE_L2) return fail(DEWI_ERR_INVALID_ARG, "unknown space %d", space);
   if (n_candidates <= 0) return DEWI_OK;
-  if (n_candidates > dewi::kMaxSortCandidates)
-    return fail(DEWI_ERR_UNSUPPORTED, "n_candidates %d exceeds %d", n_candidates, dewi::kMaxSortCandidates);
+  if (n_candidates > (1 << 30)) return fail(DEWI_ERR_UNSUPPORTED, "n_candidates %d exceeds 2^30", n_candidates);
   if (!d_dewi32 || !d_ent32) return fail(DEWI_ERR_INVALID_ARG, "null payload pointer");
   const bool records = d_out_cand != nullptr;
   if (!records) {
@@ -491,8 +488,7 @@ int dewi_knn_candidates(const void* d_E, int elem_type, int64_t n_rows, int dim,
   int rc = check_common(d_E, n_rows, dim, d_Q, n_queries, space);
   if (rc) return rc;
   if (n_candidates <= 0) return DEWI_OK;
-  if (n_candidates > dewi::kMaxSortCandidates)
-    return fail(DEWI_ERR_UNSUPPORTED, "n_candidates %d exceeds %d", n_candidates, dewi::kMaxSortCandidates);
+  if (n_candidates > (1 << 30)) return fail(DEWI_ERR_UNSUPPORTED, "n_candidates %d exceeds 2^30", n_candidates);
   if (!d_dewi32 || !d_ent32 || !d_out) return fail(DEWI_ERR_INVALID_ARG, "null payload or output pointer");
   if (id_offset < 0 || id_offset + n_rows > 0x7FFFFFFFll)
     return fail(DEWI_ERR_UNSUPPORTED, "global row ids must fit int32 (offset %lld + %lld rows)",
@@ -509,19 +505,33 @@ int dewi_knn_candidates(const void* d_E, int elem_type, int64_t n_rows, int dim,
                       id_offset, nullptr, nullptr, d_out, stream);
 }
 
+size_t dewi_merge_workspace_bytes(int n_lists, int n_queries, int list_len, int n_candidates) {
+  if (n_lists <= 0 || n_queries <= 0 || list_len <= 0 || n_candidates <= 0) return 0;
+  if (static_cast<int64_t>(n_lists) * list_len <= dewi::kMaxSortCandidates) return 0;   // sorted in LDS
+  return dewi::merge_large_workspace_bytes(n_queries, n_candidates);
+}
+
 int dewi_merge_rerank(const dewi_candidate* d_lists, int n_lists, int n_queries, int list_len, int n_candidates, int k,
-                      double eta, double entropy_pref, int64_t* d_out_ids, float* d_out_scores, void* stream) {
+                      double eta, double entropy_pref, int64_t* d_out_ids, float* d_out_scores, void* d_workspace,
+                      size_t workspace_bytes, void* stream) {
   if (!d_lists || !d_out_ids || !d_out_scores) return fail(DEWI_ERR_INVALID_ARG, "null pointer");
   if (n_lists <= 0 || n_queries <= 0 || list_len <= 0 || n_candidates <= 0)
     return fail(DEWI_ERR_INVALID_ARG, "non-positive size");
   if (k <= 0) return DEWI_OK;
   if (k > n_candidates) return fail(DEWI_ERR_K_OUT_OF_BOUNDS, "k %d exceeds candidate count %d", k, n_candidates);
-  if (static_cast<int64_t>(n_lists) * list_len > dewi::kMaxSortCandidates)
-    return fail(DEWI_ERR_UNSUPPORTED, "n_lists*list_len = %lld exceeds %d", static_cast<long long>(n_lists) * list_len,
-                dewi::kMaxSortCandidates);
-  hipError_t e = dewi::launch_merge_rerank(d_lists, n_lists, n_queries, list_len, n_candidates, k,
-                                           make_rerank(eta, entropy_pref), d_out_ids, d_out_scores,
-                                           static_cast<hipStream_t>(stream));
+  if (static_cast<int64_t>(n_lists) * list_len > 0x7FFFFFFFll || n_candidates > (1 << 30))
+    return fail(DEWI_ERR_UNSUPPORTED, "n_lists*list_len = %lld records per query", static_cast<long long>(n_lists) * list_len);
+  const size_t need = dewi_merge_workspace_bytes(n_lists, n_queries, list_len, n_candidates);
+  hipError_t e;
+  if (need == 0) {
+    e = dewi::launch_merge_rerank(d_lists, n_lists, n_queries, list_len, n_candidates, k, make_rerank(eta, entropy_pref),
+                                  d_out_ids, d_out_scores, static_cast<hipStream_t>(stream));
+  } else {
+    if (!d_workspace || workspace_bytes < need)
+      return fail(DEWI_ERR_WORKSPACE, "merge workspace %zu B < required %zu B", workspace_bytes, need);
+    e = dewi::launch_merge_rerank_large(d_lists, n_lists, n_queries, list_len, n_candidates, k, make_rerank(eta, entropy_pref),
+                                        d_workspace, d_out_ids, d_out_scores, static_cast<hipStream_t>(stream));
+  }
   return e == hipSuccess ? DEWI_OK : hip_fail(e, "merge_rerank launch");
 }
 

@@ -174,10 +174,17 @@ hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, 
                                 dewi_candidate* d_out_cand, const uint32_t* d_counts, const SegmentLayout& seg,
                                 hipStream_t stream);
 // c > kMaxSortCandidates: dense keys [n_queries][keys_per_query] in, scratch g1/g2 [n_queries][p2].
+// d_out_cand != NULL: n_out records per query (the shard's candidates) instead of final results.
 hipError_t launch_select_rerank_large(const uint64_t* d_keys, int64_t keys_per_query, int n_queries, int n_candidates,
                                       int p2, int k, const RerankParams& rp, const float* d_dewi32,
-                                      const float* d_ent32, uint64_t* d_g1, uint64_t* d_g2, int64_t* d_out_ids,
-                                      float* d_out_scores, hipStream_t stream);
+                                      const float* d_ent32, int64_t id_offset, uint64_t* d_g1, uint64_t* d_g2,
+                                      int64_t* d_out_ids, float* d_out_scores, dewi_candidate* d_out_cand, int n_out,
+                                      hipStream_t stream);
+// n_lists * list_len > kMaxSortCandidates: rank merge of the sorted shard lists through global scratch.
+size_t merge_large_workspace_bytes(int n_queries, int n_candidates);
+hipError_t launch_merge_rerank_large(const dewi_candidate* d_lists, int n_lists, int n_queries, int list_len,
+                                     int n_candidates, int k, const RerankParams& rp, void* d_ws, int64_t* d_out_ids,
+                                     float* d_out_scores, hipStream_t stream);
 hipError_t launch_merge_rerank(const dewi_candidate* d_lists, int n_lists, int n_queries, int list_len,
                                int n_candidates, int k, const RerankParams& rp, int64_t* d_out_ids,
                                float* d_out_scores, hipStream_t stream);

@@ -557,7 +557,7 @@ __global__ __launch_bounds__(kSelectThreads) void merge_rerank_kernel(const dewi
 // Large candidate counts (c > kMaxSortCandidates, i.e. k > 1024): same steps with the candidate
 // arrays in global memory instead of LDS.  One workgroup per query; g1/g2 are [n_queries][p2]
 // scratch arrays (p2 = power of two >= c).  Not a fast path — it exists so that every k the
-// reference accepts (up to k == N) is answered.
+// reference accepts (up to k == N) is answered, on one device and over doc-id shards alike.
 // ---------------------------------------------------------------------------------------------
 __device__ void bitonic_sort_desc_global(uint64_t* key, int p2) {
   const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
@@ -579,10 +579,13 @@ __device__ void bitonic_sort_desc_global(uint64_t* key, int p2) {
   __syncthreads();
 }
 
+// out_cand == nullptr: final (ids, scores), id_offset added.  out_cand != nullptr: the shard's n_out records
+// (the first n_sel real, the rest padding), exactly as select_rerank_kernel writes them.
 __global__ __launch_bounds__(kSelectThreads) void select_rerank_large_kernel(
     const uint64_t* __restrict__ keys_all, int64_t keys_per_query, int n_candidates, int p2, int k, RerankParams rp,
-    const float* __restrict__ dewi32, const float* __restrict__ ent32, uint64_t* __restrict__ g1_all,
-    uint64_t* __restrict__ g2_all, int64_t* __restrict__ out_ids, float* __restrict__ out_scores) {
+    const float* __restrict__ dewi32, const float* __restrict__ ent32, int64_t id_offset, uint64_t* __restrict__ g1_all,
+    uint64_t* __restrict__ g2_all, int64_t* __restrict__ out_ids, float* __restrict__ out_scores,
+    dewi_candidate* __restrict__ out_cand, int n_out) {
   __shared__ SelectShared sh;
   const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
   const int q = static_cast<int>(blockIdx.x);
@@ -602,6 +605,27 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_large_kernel(
   __syncthreads();
   const int n_sel = static_cast<int>(sh.count < static_cast<uint32_t>(n_candidates) ? sh.count : n_candidates);
   bitonic_sort_desc_global(g1, p2);                       // (sim desc, row asc)
+  if (out_cand != nullptr) {
+    dewi_candidate* oc = out_cand + static_cast<int64_t>(q) * n_out;
+    for (int t = tid; t < n_out; t += nt) {
+      dewi_candidate rec;
+      if (t < n_sel) {
+        const uint64_t key = g1[t];
+        const uint32_t row = key_row(key);
+        rec.sim = key_score(key);
+        rec.dewi = dewi32[row];
+        rec.ent = ent32[row];
+        rec.id = static_cast<int32_t>(static_cast<int64_t>(row) + id_offset);
+      } else {
+        rec.sim = -__builtin_inff();
+        rec.dewi = 0.f;
+        rec.ent = 0.f;
+        rec.id = -1;
+      }
+      oc[t] = rec;
+    }
+    return;
+  }
   for (int t = tid; t < p2; t += nt) {
     uint64_t k2 = kKeyEmpty;
     if (t < n_sel) {
@@ -615,17 +639,125 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_large_kernel(
   for (int j = tid; j < k && j < n_sel; j += nt) {
     const uint64_t k2 = g2[j];
     const uint32_t t = 0xFFFFFFFFu - static_cast<uint32_t>(k2);
-    out_ids[static_cast<int64_t>(q) * k + j] = key_row(g1[t]);
+    out_ids[static_cast<int64_t>(q) * k + j] = static_cast<int64_t>(key_row(g1[t])) + id_offset;
     out_scores[static_cast<int64_t>(q) * k + j] = unord_f32(static_cast<uint32_t>(k2 >> 32));
   }
 }
 
 hipError_t launch_select_rerank_large(const uint64_t* d_keys, int64_t keys_per_query, int n_queries, int n_candidates,
                                       int p2, int k, const RerankParams& rp, const float* d_dewi32,
-                                      const float* d_ent32, uint64_t* d_g1, uint64_t* d_g2, int64_t* d_out_ids,
-                                      float* d_out_scores, hipStream_t stream) {
+                                      const float* d_ent32, int64_t id_offset, uint64_t* d_g1, uint64_t* d_g2,
+                                      int64_t* d_out_ids, float* d_out_scores, dewi_candidate* d_out_cand, int n_out,
+                                      hipStream_t stream) {
   hipLaunchKernelGGL(select_rerank_large_kernel, dim3(n_queries), dim3(kSelectThreads), 0, stream, d_keys,
-                     keys_per_query, n_candidates, p2, k, rp, d_dewi32, d_ent32, d_g1, d_g2, d_out_ids, d_out_scores);
+                     keys_per_query, n_candidates, p2, k, rp, d_dewi32, d_ent32, id_offset, d_g1, d_g2, d_out_ids,
+                     d_out_scores, d_out_cand, n_out);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-shard merge with more than kMaxSortCandidates records per query (k > 128 at eight shards): the
+// shard lists are SORTED (sim desc, id asc; padding at the tail), so a record's global rank is its position
+// in its own list plus, for every other list, the number of records there that beat it — one binary search
+// per (record, other list), no sort of the concatenation.  Records ranked below n_candidates drop out; the
+// survivors land in g1 (keys, in rank order) and src (where the record lives).  Then the blend, a bitonic
+// sort of the adjusted keys in global memory, and the first k.  Scratch per query: g1 [p2] u64, g2 [p2] u64,
+// src [p2] u32 with p2 = power of two >= n_candidates.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t record_key(const dewi_candidate& rec) {
+  return rec.id >= 0 ? make_key(rec.sim, static_cast<uint32_t>(rec.id)) : kKeyEmpty;
+}
+
+__global__ __launch_bounds__(kSelectThreads) void merge_rerank_large_kernel(
+    const dewi_candidate* __restrict__ lists, int n_lists, int n_queries, int list_len, int n_candidates, int p2, int k,
+    RerankParams rp, uint64_t* __restrict__ g1_all, uint64_t* __restrict__ g2_all, uint32_t* __restrict__ src_all,
+    int64_t* __restrict__ out_ids, float* __restrict__ out_scores) {
+  __shared__ uint32_t n_valid, refused;
+  const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
+  const int q = static_cast<int>(blockIdx.x);
+  uint64_t* g1 = g1_all + static_cast<int64_t>(q) * p2;
+  uint64_t* g2 = g2_all + static_cast<int64_t>(q) * p2;
+  uint32_t* src = src_all + static_cast<int64_t>(q) * p2;
+  auto list_of = [&](int l) { return lists + (static_cast<int64_t>(l) * n_queries + q) * list_len; };
+  if (tid == 0) {
+    n_valid = 0;
+    refused = 0;
+  }
+  for (int t = tid; t < p2; t += nt) g1[t] = kKeyEmpty;
+  __syncthreads();
+  const int64_t m = static_cast<int64_t>(n_lists) * list_len;
+  for (int64_t t = tid; t < m; t += nt) {
+    const int l = static_cast<int>(t / list_len), j = static_cast<int>(t % list_len);
+    const dewi_candidate rec = list_of(l)[j];
+    if (rec.id == -2) refused = 1;   // that shard's batched path overflowed: the query is unanswered
+    if (rec.id < 0) continue;
+    atomicAdd(&n_valid, 1u);
+    const uint64_t mine = record_key(rec);
+    int64_t rank = j;                // every record ahead of it in its own list beats it
+    for (int o = 0; o < n_lists && rank < n_candidates; ++o) {
+      if (o == l) continue;
+      const dewi_candidate* other = list_of(o);
+      int lo = 0, hi = list_len;     // first position of `other` that does NOT beat `mine`
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const uint64_t ok = record_key(other[mid]);
+        const bool beats = ok > mine || (ok == mine && o < l);
+        if (beats) lo = mid + 1; else hi = mid;
+      }
+      rank += lo;
+    }
+    if (rank < n_candidates) {
+      g1[rank] = mine;
+      src[rank] = static_cast<uint32_t>(t);
+    }
+  }
+  __syncthreads();
+  if (refused) {   // same marker as the single-device batched path: ids -1, the caller re-runs the query
+    for (int j = tid; j < k; j += nt) {
+      out_ids[static_cast<int64_t>(q) * k + j] = -1;
+      out_scores[static_cast<int64_t>(q) * k + j] = __builtin_nanf("");
+    }
+    return;
+  }
+  const int n_sel = static_cast<int>(n_valid < static_cast<uint32_t>(n_candidates) ? n_valid : n_candidates);
+  auto record_at = [&](int t) {
+    const uint32_t s = src[t];
+    return list_of(static_cast<int>(s / list_len))[s % list_len];
+  };
+  for (int t = tid; t < p2; t += nt) {
+    uint64_t k2 = kKeyEmpty;
+    if (t < n_sel) {
+      const dewi_candidate rec = record_at(t);
+      const float adj = blend(rp, rec.sim, rec.dewi, rec.ent);
+      k2 = (static_cast<uint64_t>(ord_f32(adj)) << 32) | static_cast<uint64_t>(0xFFFFFFFFu - static_cast<uint32_t>(t));
+    }
+    g2[t] = k2;
+  }
+  bitonic_sort_desc_global(g2, p2);
+  for (int j = tid; j < k && j < n_sel; j += nt) {
+    const uint64_t k2 = g2[j];
+    const int t = static_cast<int>(0xFFFFFFFFu - static_cast<uint32_t>(k2));
+    out_ids[static_cast<int64_t>(q) * k + j] = record_at(t).id;
+    out_scores[static_cast<int64_t>(q) * k + j] = unord_f32(static_cast<uint32_t>(k2 >> 32));
+  }
+}
+
+size_t merge_large_workspace_bytes(int n_queries, int n_candidates) {
+  int p2 = 2;
+  while (p2 < n_candidates) p2 <<= 1;
+  return static_cast<size_t>(n_queries) * p2 * (8 + 8 + 4);
+}
+
+hipError_t launch_merge_rerank_large(const dewi_candidate* d_lists, int n_lists, int n_queries, int list_len,
+                                     int n_candidates, int k, const RerankParams& rp, void* d_ws, int64_t* d_out_ids,
+                                     float* d_out_scores, hipStream_t stream) {
+  int p2 = 2;
+  while (p2 < n_candidates) p2 <<= 1;
+  uint64_t* g1 = static_cast<uint64_t*>(d_ws);
+  uint64_t* g2 = g1 + static_cast<size_t>(n_queries) * p2;
+  uint32_t* src = reinterpret_cast<uint32_t*>(g2 + static_cast<size_t>(n_queries) * p2);
+  hipLaunchKernelGGL(merge_rerank_large_kernel, dim3(n_queries), dim3(kSelectThreads), 0, stream, d_lists, n_lists,
+                     n_queries, list_len, n_candidates, p2, k, rp, g1, g2, src, d_out_ids, d_out_scores);
   return hipGetLastError();
 }
 

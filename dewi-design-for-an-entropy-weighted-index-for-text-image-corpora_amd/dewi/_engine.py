@@ -370,6 +370,9 @@ class PipelinedSearcher:
             torch.cuda.current_stream().synchronize()
 
 
+_merge_ws: Dict[object, "torch.Tensor"] = {}      # per device: scratch of the large merge (stream-ordered reuse)
+
+
 def merge_rerank_device(lists, n_candidates: int, k: int, eta: float, entropy_pref: float, out_ids=None,
                         out_scores=None):
     """lists: int32 [n_lists, B, list_len, 4] candidate records (the all-gather result)."""
@@ -380,8 +383,16 @@ def merge_rerank_device(lists, n_candidates: int, k: int, eta: float, entropy_pr
         out_ids = torch.empty((b, k), dtype=torch.int64, device=lists.device)
     if out_scores is None:
         out_scores = torch.empty((b, k), dtype=torch.float32, device=lists.device)
+    # up to 2048 records per query are merged in LDS; beyond that (k > 128 at eight shards) through a scratch buffer
+    need = int(lib.dewi_merge_workspace_bytes(n_lists, b, list_len, int(n_candidates)))
+    ws = None
+    if need:
+        ws = _merge_ws.get(lists.device)
+        if ws is None or ws.numel() < need:
+            ws = _merge_ws[lists.device] = torch.empty(need, dtype=torch.uint8, device=lists.device)
     rc = lib.dewi_merge_rerank(nat.ptr(lists), n_lists, b, list_len, int(n_candidates), int(k), float(eta),
-                               float(entropy_pref), nat.ptr(out_ids), nat.ptr(out_scores), nat.stream_ptr())
+                               float(entropy_pref), nat.ptr(out_ids), nat.ptr(out_scores),
+                               nat.ptr(ws) if ws is not None else None, need, nat.stream_ptr())
     nat.check(rc)
     return out_ids, out_scores
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DEWI_ABI_VERSION 3
+#define DEWI_ABI_VERSION 4
 
 /* status codes */
 #define DEWI_OK 0
@@ -148,11 +148,12 @@ int dewi_prepare_queries_bf16(const float* d_Q, int n_queries, int dim, int spac
  * `n_candidates` best rows as dewi_candidate records (d_out_cand != NULL; d_out_ids/scores unused,
  * k ignored), exactly as dewi_knn_candidates.  elem_type/n_rows/dim/n_queries/n_candidates/space must equal
  * the values given to dewi_knn_scan, and both calls must come from the same host thread's tuning (together
- * they determine the path and the workspace layout).  elem_type: 0 fp32, 1 bf16.  (ABI 3: `space` added.) */
+ * they determine the path and the workspace layout).  elem_type: 0 fp32, 1 bf16.  (ABI 3: `space` added.  ABI 4:
+ * any n_candidates up to 2^30 — above 2048 the finish step sorts in the workspace, which is therefore no longer const.) */
 int dewi_knn_scan(const void* d_E, int elem_type, int64_t n_rows, int dim, const float* d_Q, int n_queries,
                   int n_candidates, int space, void* d_workspace, size_t workspace_bytes, void* stream);
 
-int dewi_knn_finish(const void* d_workspace, size_t workspace_bytes, int elem_type, int64_t n_rows, int dim,
+int dewi_knn_finish(void* d_workspace, size_t workspace_bytes, int elem_type, int64_t n_rows, int dim,
                     int n_queries, int n_candidates, int space, int k, double eta, double entropy_pref,
                     const float* d_dewi32, const float* d_ent32, int64_t id_offset, int64_t* d_out_ids,
                     float* d_out_scores, dewi_candidate* d_out_cand, void* stream);
@@ -181,10 +182,16 @@ int dewi_knn_candidates(const void* d_E, int elem_type, int64_t n_rows, int dim,
 
 /* Steps 3-5 over the concatenation of `n_lists` candidate lists per query (the all-gather result,
  * laid out [n_lists][n_queries][list_len]): global top-`n_candidates` by (sim desc, id asc), then
- * the blend and the top-k exactly as dewi_knn_rerank_f32.  Needs no workspace. */
+ * the blend and the top-k exactly as dewi_knn_rerank_f32.  Up to 2048 records per query (n_lists * list_len)
+ * are sorted in LDS and need no workspace (dewi_merge_workspace_bytes returns 0, d_workspace may be NULL);
+ * beyond that (k > 128 at eight shards) the sorted shard lists are rank-merged through a caller-owned workspace
+ * of dewi_merge_workspace_bytes(...) bytes, so that a sharded search answers every k the single device
+ * answers (the reference has no limit: backends.py:439-471).  (ABI 4: workspace arguments added.) */
+size_t dewi_merge_workspace_bytes(int n_lists, int n_queries, int list_len, int n_candidates);
+
 int dewi_merge_rerank(const dewi_candidate* d_lists, int n_lists, int n_queries, int list_len,
                       int n_candidates, int k, double eta, double entropy_pref, int64_t* d_out_ids,
-                      float* d_out_scores, void* stream);
+                      float* d_out_scores, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * A6  robust statistics — replaces scorer.RobustStats.fit (scorer.py:18-26) for n_signals

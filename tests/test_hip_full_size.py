@@ -185,3 +185,15 @@ def test_c4_eight_shards_on_one_gpu():
         assert msg is None, (j, msg)
         n_dec += int(decisive)
     assert n_dec >= 6
+    # the same exchange at k = 200 and k = 1500: 8 x 400 and 8 x 3000 records per query — beyond the 2048 an LDS sort
+    # holds, so the shard select (k = 1500) and the merge (both) run through their global-memory forms.  The sharded
+    # answer must still be the single-device answer bit for bit, and the oracle's (near-tie rules at such k).
+    for k2 in (200, 1500):
+        c2 = 2 * k2
+        lists2 = torch.stack([sh.candidates_device(Q[:2], c2) for sh in shards])
+        ids2, sc2 = eng.merge_rerank_device(lists2, c2, k2, eta, 0.0)
+        ids_w2, sc_w2 = whole.search_device(Q[:2], k2, eta, 0.0)
+        assert torch.equal(ids2, ids_w2) and torch.equal(sc2, sc_w2), k2
+        _, msg = compare_query(E, Qh[0], dewi32, ent32, k2, eta, 0.0, "cosine", ids2[0].cpu().numpy(), sc2[0].cpu().numpy(),
+                               exact_gaps=False)
+        assert msg is None, (k2, msg)

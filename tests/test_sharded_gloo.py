@@ -158,9 +158,12 @@ def _gpu_worker(rank, world, port, ret):
         Q = orc.synth_queries(6, d, seed=32)
         local = build_local_shard(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"], rank, world)
         s = ShardedSearcher(local, local.n_rows)
-        ret[rank] = {k: s.search(Q, k, 0.3, 0.2) for k in (10, 25)}
+        ret[rank] = {k: s.search(Q, k, 0.3, 0.2) for k in _GPU_KS}
     finally:
         dist.destroy_process_group()
+
+
+_GPU_KS = (10, 25, 200, 1500)     # 1500: 3000 records per shard and 6000 per merge, the global-memory select and merge
 
 
 @pytest.mark.gpu
@@ -175,10 +178,10 @@ def test_two_ranks_on_one_gpu_equal_single_device():
     cols = orc.synth_payload_columns(n, seed=31)
     Q = orc.synth_queries(6, d, seed=32)
     whole = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"])
-    for k in (10, 25):
+    for k in _GPU_KS:
         ids, sc = whole.search(Q, k, 0.3, 0.2)
         for r in (0, 1):
-            assert np.array_equal(ret[r][k][0], ids) and np.array_equal(ret[r][k][1], sc)
+            assert np.array_equal(ret[r][k][0], ids) and np.array_equal(ret[r][k][1], sc), k
 
 
 # ---- GPU: bf16 shards with a query batch large enough for the matrix-core path ---------------------
@@ -235,11 +238,12 @@ def test_two_bf16_shards_batched_path_equal_single_device(duplicates):
 
 
 # ---- CPU: world 8 with config C4's id arithmetic (1M rows per shard, offsets up to 7M) ------------
-_C4 = dict(world=8, rows_per_shard=1_000_000, real_per_shard=300, dim=24, b=4)
+_C4 = dict(world=8, rows_per_shard=1_000_000, real_per_shard=600, dim=24, b=4)
+_C4_KS = (10, 100, 200, 1500)        # 200 / 1500: 8 x 400 / 8 x 3000 records per query, beyond what one LDS sort holds
 
 
 def _c4_inputs():
-    """A sparse stand-in for the 8M-row corpus: each shard OWNS 1M doc ids but only 300 of them exist as real
+    """A sparse stand-in for the 8M-row corpus: each shard OWNS 1M doc ids but only 600 of them exist as real
     rows, at local positions j * 3331 (so global ids run up to 7 996 069): the sharded searcher's offsets,
     sizes, padding and int32 record ids are exercised at C4's scale without 8M x d of data."""
     import dewi_oracle as orc
@@ -279,7 +283,7 @@ def _c4_worker(rank, world, port, ret):
             device = torch.device("cpu")
         s = ShardedSearcher(Local(), rps, scan_fn=scan, merge_fn=_oracle_merge)
         assert s.n_total == world * rps and s.id_offset == rank * rps and s.sizes == [rps] * world
-        ret[rank] = {k: s.search(Q, k, 0.3, 0.1) for k in (10, 100)}
+        ret[rank] = {k: s.search(Q, k, 0.3, 0.1) for k in _C4_KS}
     finally:
         dist.destroy_process_group()
 
@@ -294,7 +298,7 @@ def test_world8_c4_id_arithmetic_on_cpu_gloo():
     E = orc.build_matrix(raw)
     dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
     assert len(ret) == world
-    for k in (10, 100):
+    for k in _C4_KS:
         ids0, sc0 = ret[0][k]
         for r in range(1, world):
             assert np.array_equal(ret[r][k][0], ids0) and np.array_equal(ret[r][k][1], sc0)
