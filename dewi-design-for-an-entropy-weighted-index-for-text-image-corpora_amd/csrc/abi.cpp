@@ -288,7 +288,8 @@ int batch_select(const BatchPlan& P, void* d_ws, size_t ws_bytes, int n_queries,
   const int n_seg = big ? P.big.n_seg : P.depth.n_seg;
   const int seg_cap = big ? P.big.seg_cap : P.depth.seg_cap;
   const size_t cand_off = big ? P.big.cand_off : P.depth.cand_off, cnt_off = big ? P.big.cnt_off : P.depth.cnt_off;
-  const dewi::SegmentLayout seg{n_seg, seg_cap, 1, static_cast<int64_t>(per) * seg_cap, per, 8192};
+  // counts: query-major for the 256-query pass (coalesced in the select kernel), segment-major for the depth-split pass
+  const dewi::SegmentLayout seg{n_seg, seg_cap, 1, static_cast<int64_t>(per) * seg_cap, big ? 1 : per, 8192, big ? n_seg : 1};
   for (int g = 0; g < groups && e == hipSuccess; ++g) {
     const int q0 = g * per;
     const int nq = n_queries - q0 < per ? n_queries - q0 : per;

@@ -3,92 +3,72 @@
 //
 // Same contract as the scan kernels — steps 1-3 of ExactIndex.search (reference
 // src/dewi/backends.py:420-444) — for up to 256 queries per corpus pass: the 256 x N score matrix
-// S = Qb * Eb^T is computed tile by tile with v_mfma_f32_32x32x16_bf16 and never written; an
+// S = Qb * Eb^T is computed tile by tile with v_mfma_f32_16x16x32_bf16 and never written; an
 // epilogue keeps only scores that can still reach the top c.
 //
 // Roofline: co-limited on paper.  Algorithmic bytes per pass = n_rows*dim*2 (HBM, read once);
 // flops = 2*256*n_rows*dim (393 GFLOP at C3) -> 256 flop/B against a ~310 flop/B machine balance.
-// Measured at C3: ~350 us per pass = 4.4 TB/s and 1.12 PFLOP/s (45 % of the 2.5 PF peak quoted at
-// 2.4 GHz; the kernel clocks ~1.7 GHz, at which the matrix pipe is busy 3.07 K of every 4.6 K
-// cycles = 67 %).  What bounds it is neither HBM nor LDS bandwidth (ds_read_b128 peaks at 256 B/clk
-// per CU; the A fragments ask for 128) but the two waves of a SIMD sharing one matrix pipe and one
-// vector-issue port: per 32-document tile a SIMD owes 96 MFMAs = 3072 pipe cycles, and whatever
-// the other wave does meanwhile (12 DMA pieces at ~60 issue cycles, the filter's compares/selects,
-// 1-2 survivor stores at ~90) comes out of the same SIMD — re-placing that work between the waves
-// is zero-sum (MI355X_MICROARCH.md, "Two waves per SIMD").  In-kernel stamps, cycles per tile and
-// wave: matrix block 1.6-1.8 K (48 MFMAs x 32 = 1536 ideal), side phase 1.7-1.9 K (DMA issue 0.35-
-// 0.45 K, wait for own pieces 0.15 K, filter ~1.1 K), barrier 0.7-1.1 K.  Ablations: no DMA after
-// the first tile 292 us, no filter 305 us.  Tile delivery is the other ceiling: with 8 queries (one
-// matrix wave per workgroup, seven waves only moving tiles) a pass still takes 264 us = 5.8 TB/s, the
-// LDS-DMA fill rate; 128 queries 294 us, 256 queries 345 us.  Two 32-query blocks per A fragment (half the LDS reads,
-// half the waves) need 384 query registers per wave at dim 768: 4 waves x 512 registers measured
-// 492 us (no partner wave to cover the side phase).
+// Measured at C3 (profiles/r02, r03): 292-333 us per pass = 4.6-5.2 TB/s and 1.2-1.35 PFLOP/s; the chip
+// clocks ~1.65 GHz under this load (power), at which the matrix pipe is busy ~70 % of the time.  What
+// bounds it is neither HBM nor LDS bandwidth (conflict-free ds_read_b128 at half the LDS peak) but the
+// two waves of a SIMD sharing one matrix pipe and one vector-issue port under a power-limited clock:
+// per 32-document tile a SIMD owes 192 MFMAs of 16 cycles = 3072 pipe cycles, and whatever the other
+// wave does meanwhile (6 DMA pieces at ~60 issue cycles, the filter's compares/selects, 1-2 survivor
+// stores at ~90) comes out of the same SIMD (MI355X_MICROARCH.md, "Two waves per SIMD").
+// Tile delivery is the other ceiling: with 8 queries (one matrix wave per workgroup, seven waves only
+// moving tiles) a pass still takes 264 us = 5.8 TB/s, the LDS-DMA fill rate of this structure.
 //
 // Structure (one 8-wave workgroup per CU, two waves per SIMD, persistent over 32-document tiles):
 //  * QUERIES LIVE IN REGISTERS.  Wave w owns queries 32w..32w+31 for the whole kernel: their B
-//    fragments (dim/16 x 4 VGPRs = 192 of the 256 available at dim 768) are loaded once.  No query
-//    traffic, no LDS for Q.
+//    fragments (dim/32 x 2 x 4 VGPRs = 192 of the 256 available at dim 768) are loaded once, from a
+//    FRAGMENT-ORDER image the preparation kernel writes (every load instruction of a wave reads one
+//    contiguous KiB; a row-major image made each one touch sixteen half cache lines).
 //  * DOCUMENT TILES GO THROUGH LDS BY DMA.  A tile (32 rows x dim bf16 = 48 KiB) is copied
-//    global->LDS with buffer_load_dwordx4 ... lds (1 KiB per wave-instruction, no VGPR staging)
-//    into a ring of three slots: tiles i+1 and i+2 are in flight while tile i is multiplied.  All 8
-//    waves read the same tile (A operand) with ds_read_b128, three fragments ahead of the MFMA.
+//    global->LDS with buffer_load_dwordx4 ... lds (1 KiB per wave-instruction, no VGPR staging, non-
+//    temporal) into a ring of three slots: tiles i+1 and i+2 are in flight while tile i is multiplied.
+//    All 8 waves read the same tile (A operand) with ds_read_b128, two fragments ahead of the MFMA.
 //  * BANK CONFLICTS: rows are 1536 B apart (= 0 mod 256 B), so an A-fragment read (16 lanes = 16
 //    rows, same 16-byte column unit) would be 16-way conflicted.  The LDS image is linear (DMA
 //    writes base + lane*16) and the SOURCE address is permuted instead: unit c of row r is stored
-//    at unit (c & ~15) | ((c & 15) ^ (r & 15)); reads apply the same XOR -> conflict-free (also for
-//    the 4 x 16-lane groups ds_read_b128 really uses: {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...).
-//  * A PERIOD HAS TWO HALVES PER WAVE: the matrix block (48 x [counted wait, MFMA, read 3 ahead],
+//    at unit (c & ~15) | ((c & 15) ^ (r & 15)); reads apply the same XOR -> conflict-free.
+//  * A PERIOD HAS TWO HALVES PER WAVE: the matrix block (counted wait, MFMA pair, read ahead;
 //    s_setprio 3, nothing else — a DMA instruction between the MFMAs stalled the in-order wave for
-//    60-180 cycles each and the block ran at 45-60 cycles per k-step) and the side phase (wait for
-//    own pieces of the next tile: vmcnt(0), everything outstanding is a period old; send the pieces
-//    of tile i+2; filter a finished tile).  Waves 0-3 run block(i) then side(i); waves 4-7 run
-//    side(i-1) then block(i): the two waves of a SIMD are always in opposite halves.  One s_barrier
-//    per tile.
-//  * FILTER.  D[doc][query]: lane l holds query l&31 (+32) and 16 documents.  A score passes if it is
-//    not below the query's threshold (a lower bound of its final c-th best score, from a strided
-//    1/32 sample of the corpus scanned in dense mode first).  Survivors (~32c per query over the
-//    whole pass) go to a half-segment PRIVATE to one lane: a query belongs to one wave and to two
-//    of its lanes, so the write position is a register and the record a fire-and-forget global
-//    store — no atomics.  Stores and taken branches are what costs here, not compares, so a lane
-//    compacts first (branch-free select chain: first passing score + pass mask) and the wave
-//    issues ONE predicated store; lanes with a second survivor in the same tile (one tile in
-//    four has one) go round again.  History of the filter per pass: returning global atomics
-//    1.85 ms; LDS counters + per-element predication 0.54 ms; execz branch + store per register
-//    1.8 K cycles per tile and wave; 16 predicated stores without branches 1.45 K; compaction
-//    ~1.1 K.  If a half-segment overflows (only for adversarial corpora, e.g. tens of thousands of
-//    exact duplicates of a top document) its count keeps growing and the finish kernel flags the
-//    query.
+//    60-180 cycles each) and the side phase (wait for own pieces of the next tile: vmcnt(0),
+//    everything outstanding is a period old; send the pieces of tile i+2; filter a finished tile).
+//    Waves 0-3 run block(i) then side(i); waves 4-7 run side(i-1) then block(i): the two waves of a
+//    SIMD are always in opposite halves.  One s_barrier per tile.
+//  * FILTER.  A score passes if it is not below the query's threshold (a lower bound of its final
+//    c-th best score, from a strided 1/32 sample of the corpus scanned first).  Survivors (~32c per
+//    query over the whole pass) go to a quarter-segment PRIVATE to one lane: the write position is a
+//    register and the record a fire-and-forget global store — no atomics.  Stores and taken branches
+//    are what costs here, not compares, so a lane compacts first (branch-free select chain: first
+//    passing score + pass mask) and the wave issues ONE predicated store per query half; lanes with a
+//    second survivor in the same tile go round again.  History of the filter per pass: returning
+//    global atomics 1.85 ms; LDS counters + per-element predication 0.54 ms; execz branch + store per
+//    register 1.8 K cycles per tile and wave; 16 predicated stores without branches 1.45 K;
+//    compaction ~1.1 K.  If a segment overflows (only for adversarial corpora, e.g. tens of thousands
+//    of exact duplicates of a top document) its count keeps growing and the finish kernel flags the query.
+//  * The 32x32x16 form of this kernel (round 1; one accumulator block per wave and half step) ran the
+//    same flops 4 % slower — the chip holds a higher clock on the 16x16x32 shape — and was removed in
+//    round 3; its ablations (no epilogue 305 us, no DMA after the first tile 292 us, 4 waves x 512
+//    registers 357-435 us, per-wave progress flags instead of the barrier 383 vs 355 us) are in DESIGN §4.1c.
 #include "select_common.hpp"
 
 namespace dewi {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4m __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-#ifndef DEWI_MFMA_QB
-#define DEWI_MFMA_QB 1   // 32-query blocks per wave: 1 -> 8 waves (two per SIMD, 256 registers each), 2 -> 4 waves
-                         // (one per SIMD, 492 of 512 registers at dim 768, no spills).  Measured (1M x 768, 256 queries):
-                         // 8 waves 345 us; 4 waves with both chains interleaved per k-step and the side phase after
-                         // the block 357 us; 4 waves with block 0's and block 1's chains one after the other (A
-                         // fragments read twice) so that each block is filtered during the other's chain: 425-435 us,
-                         // wherever the filter's instructions and the DMA pieces were placed and however deep the
-                         // fragment prefetch.
-#endif
-constexpr int kQB = DEWI_MFMA_QB;
-constexpr int kMfmaThreads = 64 * (8 / kQB);
+constexpr int kMfmaThreads = 512;     // 8 waves, two per SIMD
 constexpr int kTileRows = 32;
-constexpr int kQueriesPerPass = 256;  // 8 waves x 32 (or 4 x 64)
+constexpr int kQueriesPerPass = 256;  // 8 waves x 32
 #ifndef DEWI_MFMA_SAMPLE_STRIDE
 #define DEWI_MFMA_SAMPLE_STRIDE 32
 #endif
 constexpr int kSampleStride = DEWI_MFMA_SAMPLE_STRIDE;     // every 32nd tile is a sample tile
 constexpr int kMaxStagedSample = 32 * 1024;  // sample scores per query the threshold kernel keeps in LDS (128 KiB)
 constexpr int kTileBufs = 3;          // LDS ring: the tile being multiplied + two tiles of DMA in flight
-#ifndef DEWI_MFMA_AHEAD
-#define DEWI_MFMA_AHEAD 3   // A fragments in flight ahead of the MFMA being fed (4 VGPRs each; 2..10 measured equal)
-#endif
 #ifndef DEWI_MFMA_DMA_AUX
 #define DEWI_MFMA_DMA_AUX 2   // cache policy bits of the tile DMA (gfx940+: 1 = sc0, 2 = nt, 16 = sc1).  The corpus is read once:
                                // non-temporal 334 us per pass at 256 queries and 240 us at 8, default policy 355 and 264
@@ -96,14 +76,7 @@ constexpr int kTileBufs = 3;          // LDS ring: the tile being multiplied + t
 #ifndef DEWI_MFMA_PRIO
 #define DEWI_MFMA_PRIO 1
 #endif
-#ifndef DEWI_MFMA_SHAPE16
-#define DEWI_MFMA_SHAPE16 1   // 1: mfma_scan_bf16_s16 (v_mfma_f32_16x16x32_bf16), 0: mfma_scan_bf16 (32x32x16)
-#endif
-constexpr bool kShape16 = DEWI_MFMA_SHAPE16 != 0;
-constexpr int kSegPerBlock = kShape16 ? 4 : 2;   // lane-private survivor segments per workgroup and query
-#ifndef DEWI_MFMA_ABLATE
-#define DEWI_MFMA_ABLATE 0   // timing experiments only: 1 no epilogue, 2 no DMA after the first tile, 3 no MFMA
-#endif
+constexpr int kSegPerBlock = 4;       // lane-private survivor quarter-segments per workgroup and query
 
 using GlobalPtr = const void __attribute__((address_space(1)))*;
 using LdsPtr = void __attribute__((address_space(3)))*;
@@ -112,13 +85,27 @@ using LdsPtr = void __attribute__((address_space(3)))*;
 // of the 32-padded block are zero.  One wave per query row.
 // qn2 (optional): ||bf16-rounded prepared query||^2 per output row (float64-summed, one rounding), for the l2 score of
 // the depth-split pass.
+// frag_order != 0 (dim % 32 == 0; the 256-query kernel's input): the image is written in the order mfma_scan_bf16_s16
+// loads its B fragments instead of row-major — the 8 columns 8j..8j+7 of query q (k-step s = j / 4, lane group g = j % 4)
+// go to 16-byte unit (((q / 32) * 2 + (q / 16) % 2) * (dim / 32) + s) * 64 + 16 g + q % 16 — so that each of a wave's
+// fragment loads reads one contiguous KiB.
+__device__ __forceinline__ int64_t fragment_unit(int q, int j, int dim) {
+  return (static_cast<int64_t>((q >> 5) * 2 + ((q >> 4) & 1)) * (dim >> 5) + (j >> 2)) * 64 + 16 * (j & 3) + (q & 15);
+}
+
 __global__ __launch_bounds__(kWave) void prepare_queries_bf16(const float* __restrict__ Q, uint16_t* __restrict__ Qb,
-                                                              int n_queries, int dim, int space, float* __restrict__ qn2) {
+                                                              int n_queries, int dim, int space, float* __restrict__ qn2,
+                                                              int frag_order) {
   const int lane = lane_id();
   const int row = static_cast<int>(blockIdx.x);
   uint16_t* o = Qb + static_cast<int64_t>(row) * dim;
   if (row >= n_queries) {
-    for (int j = lane; j < dim; j += kWave) o[j] = 0;
+    if (frag_order) {
+      for (int j = lane; j < (dim >> 3); j += kWave)
+        reinterpret_cast<uint4*>(Qb)[fragment_unit(row, j, dim)] = uint4{0u, 0u, 0u, 0u};
+    } else {
+      for (int j = lane; j < dim; j += kWave) o[j] = 0;
+    }
     if (qn2 != nullptr && lane == 0) qn2[row] = 0.f;
     return;
   }
@@ -161,7 +148,10 @@ __global__ __launch_bounds__(kWave) void prepare_queries_bf16(const float* __res
         r.z = to_bf16(scale ? __fdiv_rn(v[u].z, norm) : v[u].z);
         r.w = to_bf16(scale ? __fdiv_rn(v[u].w, norm) : v[u].w);
         out2 += square_f64(widen(r.x)) + square_f64(widen(r.y)) + square_f64(widen(r.z)) + square_f64(widen(r.w));
-        reinterpret_cast<u16x4p*>(o)[j] = r;
+        if (frag_order)   // columns 4j..4j+3 = half (j & 1) of the 8-column group j >> 1
+          reinterpret_cast<u16x4p*>(Qb)[fragment_unit(row, j >> 1, dim) * 2 + (j & 1)] = r;
+        else
+          reinterpret_cast<u16x4p*>(o)[j] = r;
       }
     }
     if (qn2 != nullptr) {
@@ -170,6 +160,7 @@ __global__ __launch_bounds__(kWave) void prepare_queries_bf16(const float* __res
     }
     return;
   }
+  // (any other dim: row-major only — the fragment order is asked for by the 256-query kernel alone, dim % 128 == 0)
   float norm = 1.f;
   bool scale = false;
   if (space == DEWI_SPACE_COSINE) {
@@ -190,428 +181,29 @@ __global__ __launch_bounds__(kWave) void prepare_queries_bf16(const float* __res
   }
 }
 
-// KS = dim / 16 MFMA k-steps (dim % 128 == 0, dim <= 768).
-// Tiles handled by this launch: t = first_tile + i * tile_stride, i in [0, n_tiles).
-template <int KS, bool DENSE>
-__global__ __launch_bounds__(kMfmaThreads, 2 / kQB) void mfma_scan_bf16(
-    const uint16_t* __restrict__ E, int64_t n_rows, const uint16_t* __restrict__ Qb, int64_t n_tiles,
-    int64_t tile_stride, const float* __restrict__ thr, uint64_t* __restrict__ out, int64_t out_stride,
-    uint32_t* __restrict__ cnt, int n_active) {
-  // DENSE (the sample pass): `out` is a float array: out[q * out_stride + (2*blockIdx.x + h) * 16 + j] = the best
-  //        score register j of that lane saw over this workgroup's (strided) tiles — 32 group maxima per workgroup.
-  // filter: raw records out[((2*blockIdx.x + h) * 256 + q) * out_stride + slot], cnt[(2*blockIdx.x + h) * 256 + q].
-#if defined(__HIP_DEVICE_COMPILE__)  // the body holds gfx950 inline asm: the host pass only needs the launch stub
-  constexpr int DIM = KS * 16;
-  constexpr int UPR = DIM / 8;                     // 16-byte units per row
-  constexpr int TILE_BYTES = kTileRows * DIM * 2;
-  constexpr int PIECES = TILE_BYTES / 1024;        // 1 KiB DMA pieces per tile (= KS)
-  constexpr int NW = kMfmaThreads / kWave;         // waves per workgroup
-  constexpr int PPW = PIECES / NW;                 // pieces per wave
-  static_assert(KS % 8 == 0 && KS <= 48, "dim must be a multiple of 128, at most 768");
-  extern __shared__ __attribute__((aligned(16))) char lds[];  // kTileBufs x TILE_BYTES
-
-  const int lane = lane_id();
-  const int wave = static_cast<int>(threadIdx.x) >> 6;
-  const int r = lane & 31, h = lane >> 5;
-
-  // ---- query fragments (B operand): two 32-query blocks per wave; lane holds
-  //      Qb[64*wave + 32*b + r][16 s + 8 h .. +7]
-  // n_active = real queries in this group of 256; the rest is zero padding.  A padding query scores 0
-  // against every document and its sample threshold is 0 too, so it would "pass" everywhere and bury the
-  // epilogue in stores: its threshold is forced to +inf below.  A wave none of whose queries is real skips
-  // the matrix block and the filter altogether; it still moves its share of every tile and meets the
-  // barrier.
-  const bool active = 32 * kQB * __builtin_amdgcn_readfirstlane(wave) < n_active;
-  bf16x8 qf[kQB][KS];
-#pragma unroll
-  for (int b = 0; b < kQB; ++b) {
-    const bf16x8* qp = reinterpret_cast<const bf16x8*>(Qb + static_cast<int64_t>(32 * kQB * wave + 32 * b + r) * DIM + 8 * h);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) qf[b][s] = qp[active ? 2 * s : 0];
-  }
-  float thr_l[kQB];
-#pragma unroll
-  for (int b = 0; b < kQB; ++b)
-    thr_l[b] = DENSE ? -__builtin_inff()
-                     : (32 * kQB * wave + 32 * b + r < n_active ? thr[32 * kQB * wave + 32 * b + r] : __builtin_inff());
-  // Pin the compiler's waits for these loads HERE, before any DMA is in flight: their first real use
-  // is inside the tile loop, and a compiler-inserted vmcnt(0) there would drain the prefetch of the
-  // next tile on every iteration.
-#pragma unroll
-  for (int s = 0; s < KS; ++s) {
-#pragma unroll
-    for (int b = 0; b < kQB; ++b) asm volatile("" ::"v"(qf[b][s]));
-  }
-#pragma unroll
-  for (int b = 0; b < kQB; ++b) asm volatile("" ::"v"(thr_l[b]));
-
-  // ---- per-lane DMA source offsets (bytes from the tile's first row).  The swizzle repeats every
-  // 16 rows (= KS/2 pieces), so where that is a whole number of this wave's pieces (KS % (2 NW) == 0)
-  // piece i and piece i + VO differ by the constant 16 * DIM * 2 bytes, which goes into the
-  // instruction's scalar offset: VO = KS/(2 NW) registers instead of PPW = KS/NW.
-  constexpr int VO = (KS % (2 * NW) == 0) ? KS / (2 * NW) : PPW;
-  uint32_t voff[VO];
-#pragma unroll
-  for (int i = 0; i < VO; ++i) {
-    const int piece = i * NW + wave;
-    const int x = piece * 64 + lane;               // LDS unit this lane fills
-    const int row = x / UPR, cp = x % UPR;
-    const int c = (cp & ~15) | ((cp & 15) ^ (row & 15));
-    voff[i] = static_cast<uint32_t>(row * (DIM * 2) + c * 16);
-  }
-  // ---- per-lane A-fragment read offsets inside a tile buffer
-  // unit (2j) ^ z of row r, j = k-step mod 8: eight address registers (a v_xor per read instead would
-  // save seven of them but costs a vector-issue slot per k-step, and issue slots are what this kernel
-  // runs out of: see the roofline note at the top).
-  const int z = (r & 15) ^ h;
-  uint32_t a_addr[8];  // LDS byte addresses for ring slot 0; advanced to the next slot in place every tile
-#pragma unroll
-  for (int j = 0; j < 8; ++j)
-    a_addr[j] = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((LdsPtr)(lds))) +
-                static_cast<uint32_t>(r * UPR * 16 + 16 * ((2 * j) ^ z));
-
-  // A tile is fetched through a buffer descriptor whose base is the tile's first row and whose
-  // size is the tile's valid bytes: rows past the end of the corpus (partial last tile) read as
-  // zeros through the hardware range check, and the per-lane part of the address is one 32-bit
-  // register per piece.
-  const char* Eb = reinterpret_cast<const char*>(E);
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  auto tile_rsrc = [&](int64_t tile_index) {
-    const int64_t row0 = tile_index * kTileRows;
-    const int64_t left = n_rows - row0;
-    const int valid_rows = left < kTileRows ? static_cast<int>(left) : kTileRows;
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Eb + row0 * (DIM * 2)), 0, valid_rows * (DIM * 2),
-                                             0x00020000);
-  };
-  auto issue_piece = [&](__amdgpu_buffer_rsrc_t rsrc, int buf, int i) {
-    char* l = lds + buf * TILE_BYTES + (i * NW + wave_u) * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)(l), 16, voff[i % VO], (i / VO) * (16 * DIM * 2), 0, DEWI_MFMA_DMA_AUX);
-  };
-
-  // ---- survivor segments.  Queries belong to exactly one wave and to exactly two of its lanes
-  // (l and l+32, which hold different documents), so each LANE owns a private half-segment per
-  // query block and its slot counter is a plain register: no atomics of any kind.
-  // segment index = 2*blockIdx.x + h; keys at out[(segment*256 + q) * out_stride + slot].
-  // off[b] = BYTE offset into `out` of the next free record of this lane's half-segment (32-bit: the
-  // whole candidate area is far below 4 GiB); the stores address `out` as SGPR base + VGPR offset.
-  uint32_t off[kQB];
-#pragma unroll
-  for (int b = 0; b < kQB; ++b)
-    off[b] = ((static_cast<uint32_t>(blockIdx.x) * 2 + h) * kQueriesPerPass + (32 * kQB * wave + 32 * b + r)) *
-             static_cast<uint32_t>(out_stride) * 8u;
-
-  const int64_t first = static_cast<int64_t>(blockIdx.x);
-  const int64_t step = static_cast<int64_t>(gridDim.x);
-  // Prologue: the first two tiles of this workgroup go out at once (ring slots 0 and 1).
-  if (first < n_tiles) {
-    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(first * tile_stride);
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) issue_piece(rs, 0, i);
-  }
-  if (first + step < n_tiles && DEWI_MFMA_ABLATE != 2) {
-    const __amdgpu_buffer_rsrc_t rs = tile_rsrc((first + step) * tile_stride);
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) issue_piece(rs, 1, i);
-  }
-  // the survivor stores take their base address from an SGPR pair: make the pointer provably wave-uniform
-  // (with 512 registers per wave hipcc otherwise hands the inline asm a VGPR pair for the "s" operand)
-  const uint64_t out_bits = reinterpret_cast<uint64_t>(out);
-  uint64_t* const out_uniform = reinterpret_cast<uint64_t*>(
-      (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(out_bits >> 32)))) << 32) |
-      static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(out_bits))));
-  // Sample pass (DENSE): instead of writing every score (256 x 31 K scattered 4-byte stores per pass, and as many
-  // values for the threshold kernel to read back) each lane keeps, per accumulator register, the MAXIMUM over the
-  // tiles of this workgroup.  The c-th largest of those group maxima (gridDim x 2 halves x 16 registers = 8192
-  // groups per query) is a lower bound of the query's final c-th best score, as the c-th best sample score was —
-  // c different documents reach it — and with 8192 groups >> c it is within ~1 % of that bound's survivor rate.
-  float mx[DENSE ? kQB : 1][16];
-  if constexpr (DENSE) {
-#pragma unroll
-    for (int b = 0; b < kQB; ++b) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) mx[b][j] = -__builtin_inff();
-    }
-  }
-  // The epilogue of tile i: D[doc = (j&3) + 8*(j>>2) + 4*h][query = 32*wave + r].
-  auto epilogue = [&](f32x16 (&acc)[kQB], int64_t i) {
-    const int64_t row0 = i * tile_stride * kTileRows;
-    const int doc0 = static_cast<int>(row0) + 4 * h;           // n_rows < 2^32 and row0 < n_rows
-    if (row0 + kTileRows > n_rows) {                           // partial last tile: padding rows never pass
-#pragma unroll
-      for (int b = 0; b < kQB; ++b) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-          if (row0 + (j & 3) + 8 * (j >> 2) + 4 * h >= n_rows) acc[b][j] = -__builtin_inff();
-      }
-    }
-#pragma unroll
-    for (int b = 0; b < kQB; ++b) {
-      if (DEWI_MFMA_ABLATE == 1) {
-        asm volatile("" ::"v"(acc[b]));
-      } else if constexpr (DENSE) {
-        // sample pass: every accumulator register keeps the best score it has seen (rows past the corpus end were
-        // set to -inf above; fmax ignores NaN, which can only make the bound lower, never invalid)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) mx[b][j] = __builtin_fmaxf(mx[b][j], acc[b][j]);
-      } else {
-        // Filtering a lane's 16 scores.  What this costs is NOT the compares: vector ALU work of the
-        // filtering wave issues in the gaps of the partner wave's MFMAs (an MFMA holds the SIMD's vector
-        // issue for 8 of its 32 cycles).  It is the global stores — ~90 cycles of issue each, with however
-        // few lanes enabled (measured: one predicated store per accumulator register, 16 per tile and
-        // wave, 1.45 K cycles; an execz branch around each store, ~5 taken per tile, 1.8 K) — and taken
-        // branches.  So a lane first COMPACTS: a branch-free select chain keeps its first passing score
-        // (and that score's row) and counts the passing ones; one predicated store then serves every
-        // lane of the wave.  A lane rarely has a second survivor in the same tile (~0.5 %, i.e. one tile
-        // in four has such a lane somewhere in the wave); those go round again: chain over the registers
-        // behind the one already stored, one more store.
-        // The per-store capacity check is hoisted: one ballot per tile decides whether every lane has room
-        // for 16 more records; only an (adversarial) nearly full half-segment takes the checked path below.
-        const uint32_t seg_q = (static_cast<uint32_t>(blockIdx.x) * 2 + h) * kQueriesPerPass + (32 * kQB * wave + 32 * b + r);
-        const uint32_t end_bytes = (seg_q + 1u) * static_cast<uint32_t>(out_stride) * 8u;
-        const bool tight = off[b] + 16u * 8u > end_bytes;   // also true once the segment has overflowed
-        if (__builtin_amdgcn_ballot_w64(tight) == 0ull && DEWI_MFMA_ABLATE != 4) {
-          // raw record: high word = document row, low word = fp32 score bits (the finish kernel builds the
-          // ordered key).  NaN passes (NumPy ranks NaN first): the test is "not below".
-          auto store_where = [&](uint32_t flag, uint32_t row_off, float score) {
-            const uint64_t rec = (static_cast<uint64_t>(static_cast<uint32_t>(doc0) | row_off) << 32) | __float_as_uint(score);
-            uint64_t saved_exec;
-            asm volatile(
-                "v_cmp_ne_u32 vcc, 0, %[f]\n\t"
-                "s_and_saveexec_b64 %[sv], vcc\n\t"
-                "global_store_dwordx2 %[off], %[rec], %[base]\n\t"
-                "v_add_u32 %[off], 8, %[off]\n\t"
-                "s_mov_b64 exec, %[sv]"
-                : [off] "+v"(off[b]), [sv] "=&s"(saved_exec)
-                : [f] "v"(flag), [rec] "v"(rec), [base] "s"(out_uniform)
-                : "vcc", "memory");
-          };
-          // Three vector instructions per register: the compare, a select for the score, and an
-          // add-with-carry that shifts the lane's pass bit into a mask (mask = 2 mask + pass), from which
-          // the count (popcount) and the first passing register (lowest set bit) follow at the end.
-          uint32_t mask = 0;
-          float first = 0.f;
-#pragma unroll
-          for (int j = 15; j >= 0; --j) {   // descending, so the LOWEST passing register is the one kept
-            const bool pass = !(acc[b][j] < thr_l[b]);
-            first = pass ? acc[b][j] : first;
-            mask = mask + mask + (pass ? 1u : 0u);    // bit (15 - j') of the final mask ... register j ends at bit j
-          }
-          uint32_t n_pass = static_cast<uint32_t>(__builtin_popcount(mask));
-          const uint32_t j0 = static_cast<uint32_t>(__builtin_ctz(mask | 0x10000u));   // first passing register (16: none)
-          uint32_t ro = (j0 & 3u) + 8u * (j0 >> 2);
-          store_where(n_pass, ro, first);
-          uint32_t more = n_pass > 1u ? 1u : 0u;
-          while (__builtin_amdgcn_ballot_w64(more != 0u) != 0ull) {
-            uint32_t ro_next = 0;
-            float next = 0.f;
-#pragma unroll
-            for (int j = 15; j >= 1; --j) {   // row offsets grow with j: "behind the stored one" = larger offset
-              const uint32_t roj = static_cast<uint32_t>((j & 3) + 8 * (j >> 2));
-              const bool pass = !(acc[b][j] < thr_l[b]) && roj > ro;
-              next = pass ? acc[b][j] : next;
-              ro_next = pass ? roj : ro_next;
-            }
-            store_where(more, ro_next, next);
-            ro = more ? ro_next : ro;
-            n_pass -= more;
-            more = n_pass > 1u ? 1u : 0u;
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const bool pass = !(acc[b][j] < thr_l[b]);
-            if (pass) {
-              if (off[b] < end_bytes && DEWI_MFMA_ABLATE != 4) {
-                out[off[b] >> 3] = (static_cast<uint64_t>(static_cast<uint32_t>(doc0 + (j & 3) + 8 * (j >> 2))) << 32) |
-                                   __float_as_uint(acc[b][j]);
-              }
-              off[b] += 8u;   // keeps counting past the end: the finish kernel sees count > capacity
-            }
-          }
-        }
-      }
-    }
-  };
-  // The two waves of a SIMD run half a period apart: waves 0..NW/2-1 multiply tile i and then
-  // filter it; waves NW/2.. filter tile i-1 FIRST and multiply tile i afterwards.  One wave of each
-  // SIMD is therefore in its matrix block while the other is in its (matrix-pipe-idle) epilogue,
-  // instead of both competing for the pipe and then both leaving it idle.
-  const bool deferred = kQB == 1 && wave_u >= NW / 2;   // one wave per SIMD (kQB = 2): nothing to stagger against
-#ifdef DEWI_MFMA_STAMPS
-  uint64_t st_dma = 0, st_vm = 0, st_wait = 0, st_mfma = 0, st_epi = 0, st_t0 = __builtin_readcyclecounter(), st_tiles = 0;
-#define ST_NOW() __builtin_readcyclecounter()
-#endif
-  f32x16 acc[kQB];
-  int64_t prev = -1;
-  int buf = 0;
-  // first tile: its pieces are the older half of the prologue's DMA
-  if (first + step < n_tiles && DEWI_MFMA_ABLATE != 2) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  for (int64_t i = first; i < n_tiles; i += step) {
-    // tile i+2 is fetched while tile i is multiplied: a tile has two whole iterations to land
-    const bool has_next2 = (i + 2 * step < n_tiles) && DEWI_MFMA_ABLATE != 2;
-#ifdef DEWI_MFMA_STAMPS
-    const uint64_t st_a = ST_NOW();
-#endif
-    // One barrier per tile: (a) every wave's pieces of this tile have landed (each waited for its own in
-    // its side phase), (b) every wave has finished reading the slot of tile i-1, which the DMA of tile i+2
-    // refills.  Every wave idles ~0.7-1.1 K cycles of a 4.6 K-cycle period here, but the barrier is also
-    // what keeps the two waves of a SIMD in complementary phases: per-wave progress flags in LDS (block
-    // on "tile landed", DMA on "slot free", a tile of slack) ran 383 us against 355.
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    const int buf2 = buf + 2 >= kTileBufs ? buf + 2 - kTileBufs : buf + 2;
-
-    // A fragments are read kAhead k-steps ahead of the MFMA that consumes them.  hipcc sinks plain LDS
-    // loads back next to their use at this register pressure, so the reads and their counted waits are
-    // inline asm: LDS returns data in order, hence before step s may start at most the kAhead younger
-    // reads may be pending.  The wait statement takes the fragment as an in/out operand so that the
-    // MFMA cannot be scheduled above it.  No other LGKM operation is issued between the first read and
-    // the last wait.  The first kAhead reads go out right behind the barrier — for the deferred waves
-    // that is BEFORE their epilogue, so their matrix block starts on fragments that are already there.
-    constexpr int kAhead = DEWI_MFMA_AHEAD < KS - 1 ? DEWI_MFMA_AHEAD : KS - 1;
-    u32x4m ring[kAhead + 1];
-    auto read_fragment = [&](u32x4m& dst, int s) {
-      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(a_addr[s & 7]), "n"(256 * (s >> 3)));
-    };
-#pragma unroll
-    for (int s = 0; s < kAhead && active; ++s) read_fragment(ring[s], s);
-
-    // The half of a period a wave does NOT spend in its matrix block: wait for its pieces of the next
-    // tile, send the pieces of tile i+2, filter a finished tile.  The DMA is issued here and not between
-    // the MFMAs: a vector-memory instruction that queues up stalls the in-order wave behind it, which
-    // showed as gaps in the matrix pipe (~45-60 cycles per k-step instead of 32).
-    //   vmcnt(0): the only vector-memory operations outstanding are this wave's pieces of tile i+1 and
-    //   the survivor stores of its previous epilogue, all a whole period old — no stall, and no
-    //   dependence on how many stores there were.  Tile i+2 goes into the ring slot of tile i-1, which
-    //   every wave finished reading before the barrier above.
-    auto side_phase = [&](bool filter, int64_t filter_tile) {
-#ifdef DEWI_MFMA_STAMPS
-      const uint64_t sp0 = ST_NOW();
-#endif
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef DEWI_MFMA_STAMPS
-      const uint64_t sp1 = ST_NOW();
-#endif
-      if (has_next2) {
-        const __amdgpu_buffer_rsrc_t next_rsrc = tile_rsrc((i + 2 * step) * tile_stride);
-#pragma unroll
-        for (int p = 0; p < PPW; ++p) issue_piece(next_rsrc, buf2, p);
-      }
-#ifdef DEWI_MFMA_STAMPS
-      const uint64_t sp2 = ST_NOW();
-      st_vm += sp1 - sp0;
-      st_dma += sp2 - sp1;
-#endif
-      if (filter && active) epilogue(acc, filter_tile);
-    };
-
-#ifdef DEWI_MFMA_STAMPS
-    const uint64_t st_b = ST_NOW();
-#endif
-    if (deferred) side_phase(prev >= 0, prev);
-#ifdef DEWI_MFMA_STAMPS
-    const uint64_t st_c = ST_NOW();
-#endif
-    if (active) {
-    if (DEWI_MFMA_PRIO) __builtin_amdgcn_s_setprio(3);   // the matrix block wins issue arbitration against the other wave's epilogue
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      u32x4m& cur = ring[s % (kAhead + 1)];
-      if (s + kAhead < KS) read_fragment(ring[(s + kAhead) % (kAhead + 1)], s + kAhead);
-      asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(cur) : "n"((KS - 1 - s) < kAhead ? (KS - 1 - s) : kAhead));
-      const bf16x8 a = __builtin_bit_cast(bf16x8, cur);
-      if (DEWI_MFMA_ABLATE != 3) {
-#pragma unroll
-        for (int b = 0; b < kQB; ++b) {
-          // the first k-step accumulates onto a literal zero: no 16 v_mov per tile to clear the accumulator
-          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[b][s], s == 0 ? zero : acc[b], 0, 0, 0);
-        }
-      } else {
-        asm volatile("" ::"v"(a));
-      }
-    }
-
-    if (DEWI_MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
-    }
-#ifdef DEWI_MFMA_STAMPS
-    asm volatile("" ::"v"(acc[0]));
-    const uint64_t st_w = ST_NOW();
-    const uint64_t st_d = st_w;
-#endif
-    if (!deferred) side_phase(true, i);
-#ifdef DEWI_MFMA_STAMPS
-    const uint64_t st_e = ST_NOW();
-    st_wait += st_b - st_a;
-    st_mfma += st_w - st_c;
-    st_epi += (st_c - st_b) + (st_e - st_d);
-    ++st_tiles;
-#endif
-    prev = i;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) a_addr[j] = buf == kTileBufs - 1 ? a_addr[j] - (kTileBufs - 1) * TILE_BYTES : a_addr[j] + TILE_BYTES;
-    buf = buf == kTileBufs - 1 ? 0 : buf + 1;
-  }
-  if (deferred && prev >= 0 && active) epilogue(acc, prev);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef DEWI_MFMA_STAMPS
-  if (!DENSE && blockIdx.x == 3 && lane == 0)
-    printf("wave %d tiles %llu total %llu dma-issue/tile %llu vmwait/tile %llu | barrier %llu mfma %llu epilogue %llu (cycles per tile: %llu / %llu / %llu)\n", wave, (unsigned long long)st_tiles, (unsigned long long)(ST_NOW() - st_t0), (unsigned long long)(st_dma / st_tiles), (unsigned long long)(st_vm / st_tiles),
-           (unsigned long long)st_wait,
-           (unsigned long long)st_mfma, (unsigned long long)st_epi, (unsigned long long)(st_wait / st_tiles),
-           (unsigned long long)(st_mfma / st_tiles), (unsigned long long)(st_epi / st_tiles));
-#endif
-  if constexpr (!DENSE) {
-#pragma unroll
-    for (int b = 0; b < kQB; ++b) {
-      const uint32_t seg_q = (static_cast<uint32_t>(blockIdx.x) * 2 + h) * kQueriesPerPass + (32 * kQB * wave + 32 * b + r);
-      cnt[seg_q] = (off[b] >> 3) - seg_q * static_cast<uint32_t>(out_stride);
-    }
-  } else if (active) {
-    // group maxima of this lane: 16 consecutive floats (64 B) of the query's row
-#pragma unroll
-    for (int b = 0; b < kQB; ++b) {
-      f32x4v* dst = reinterpret_cast<f32x4v*>(reinterpret_cast<float*>(out) +
-                                              static_cast<int64_t>(32 * kQB * wave + 32 * b + r) * out_stride +
-                                              (static_cast<int64_t>(blockIdx.x) * 2 + h) * 16);
-#pragma unroll
-      for (int j4 = 0; j4 < 4; ++j4) dst[j4] = f32x4v{mx[b][4 * j4], mx[b][4 * j4 + 1], mx[b][4 * j4 + 2], mx[b][4 * j4 + 3]};
-    }
-  }
-#endif
-}
-
 // ---------------------------------------------------------------------------------------------
-// The same pass on v_mfma_f32_16x16x32_bf16 (round 2).  Equal FLOPs, LDS bytes and matrix-pipe cycles per tile —
-// per 32 columns four 16-cycle MFMAs (2 document halves x 2 query halves) instead of two 32-cycle ones — but the
-// chip holds a HIGHER CLOCK on this shape in a power-limited loop (MI355X_MICROARCH.md, DVFS give-back item 7;
-// cdna_hip_programming.md §5.4 rule 28): timing experiment with the operands of the 32x32 kernel pushed through
-// 16x16x32 instructions 282-310 us against 336.  Same structure as mfma_scan_bf16 (queries in registers, tile ring by
-// LDS-DMA with the XOR swizzle, matrix block / side phase halves of the two waves of a SIMD, lane-private survivor
-// segments); what changes is the fragment geometry:
+// The pass itself, on v_mfma_f32_16x16x32_bf16: per 32 columns four 16-cycle MFMAs (2 document halves x 2 query
+// halves).  Fragment geometry:
 //   lane l = (c = l & 15, g = l >> 4).  k-step s covers columns 32 s .. 32 s + 31; lane group g holds columns 32 s + 8 g .. +7.
 //   B (queries, registers): qf[qh][s] = Qb[32 wave + 16 qh + c][32 s + 8 g .. +7], qh = 0, 1        (2 x 24 x 4 = 192 VGPRs at dim 768)
 //   A (documents, LDS):     fragment f = 2 s + dh = rows 16 dh + c of the tile, 16-byte unit 4 s + g, swizzled as the DMA
-//                           wrote it: unit (u & ~15) | ((u & 15) ^ (row & 15)) — still conflict-free for the 4 x 16-lane
+//                           wrote it: unit (u & ~15) | ((u & 15) ^ (row & 15)) — conflict-free for the 4 x 16-lane
 //                           groups of ds_read_b128 (rows {0-3, 12-15} of group g with rows {4-11} of group g+1).
 //   D:                      acc[dh][qh][t] = score of document 16 dh + 4 g + t against query 32 wave + 16 qh + c.
 // A lane therefore holds TWO queries (qh = 0, 1) with eight documents each; a query belongs to four lanes (g = 0..3) of
 // one wave: quarter-segments, segment index 4 blockIdx.x + g, two slot counters per lane.
+// KS = dim / 16 (dim % 128 == 0, dim <= 768).  Tiles handled by a launch: t = first_tile + i * tile_stride.
 // ---------------------------------------------------------------------------------------------
 typedef float f32x4a __attribute__((ext_vector_type(4)));
 
-template <int KS, bool DENSE>   // KS = dim / 16 as for mfma_scan_bf16 (dim % 128 == 0, dim <= 768)
+template <int KS, bool DENSE>
 __global__ __launch_bounds__(512, 2) void mfma_scan_bf16_s16(
     const uint16_t* __restrict__ E, int64_t n_rows, const uint16_t* __restrict__ Qb, int64_t n_tiles,
     int64_t tile_stride, const float* __restrict__ thr, uint64_t* __restrict__ out, int64_t out_stride,
     uint32_t* __restrict__ cnt, int n_active) {
   // DENSE (sample pass): out is a float array: out[q * out_stride + (4 * blockIdx.x + g) * 8 + 4 dh + t] = the best score
   //        that accumulator register saw over this workgroup's (strided) tiles — 32 group maxima per workgroup and query.
-  // filter: raw records out[((4 * blockIdx.x + g) * 256 + q) * out_stride + slot], cnt[(4 * blockIdx.x + g) * 256 + q].
+  // filter: raw records out[((4 * blockIdx.x + g) * 256 + q) * out_stride + slot], cnt[q * 4 gridDim.x + 4 * blockIdx.x + g].
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int DIM = KS * 16;
   constexpr int KS2 = KS / 2;                      // 32-column k-steps
@@ -630,12 +222,14 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_bf16_s16(
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const bool active = 32 * wave_u < n_active;
 
+  // Qb is the FRAGMENT-ORDER image prepare_queries_bf16 writes (frag_order): unit ((2 wave + qh) * KS2 + s) * 64 + lane
+  // holds Qb[32 wave + 16 qh + c][32 s + 8 g .. +7] — one contiguous KiB per load instruction of the wave
   bf16x8 qf[2][KS2];
 #pragma unroll
   for (int qh = 0; qh < 2; ++qh) {
-    const bf16x8* qp = reinterpret_cast<const bf16x8*>(Qb + static_cast<int64_t>(32 * wave + 16 * qh + c) * DIM + 8 * g);
+    const bf16x8* qp = reinterpret_cast<const bf16x8*>(Qb) + static_cast<int64_t>(2 * wave + qh) * KS2 * 64 + lane;
 #pragma unroll
-    for (int s = 0; s < KS2; ++s) qf[qh][s] = qp[active ? 4 * s : 0];
+    for (int s = 0; s < KS2; ++s) qf[qh][s] = qp[active ? 64 * s : 0];
   }
   float thr_l[2];
 #pragma unroll
@@ -650,7 +244,9 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_bf16_s16(
   }
   asm volatile("" ::"v"(thr_l[0]), "v"(thr_l[1]));
 
-  // ---- DMA source offsets: as in mfma_scan_bf16 (the LDS image of a tile is the same)
+  // ---- per-lane DMA source offsets (bytes from the tile's first row).  The swizzle repeats every 16 rows (= KS/2
+  // pieces), so piece i and piece i + VO differ by the constant 16 * DIM * 2 bytes, which goes into the instruction's
+  // scalar offset: VO = KS/(2 NW) registers instead of PPW = KS/NW.
   constexpr int VO = (KS % (2 * NW) == 0) ? KS / (2 * NW) : PPW;
   uint32_t voff[VO];
 #pragma unroll
@@ -865,8 +461,10 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_bf16_s16(
   if constexpr (!DENSE) {
 #pragma unroll
     for (int qh = 0; qh < 2; ++qh) {
-      const uint32_t seg_q = (static_cast<uint32_t>(blockIdx.x) * 4 + g) * kQueriesPerPass + (32 * wave + 16 * qh + c);
-      cnt[seg_q] = (off[qh] >> 3) - seg_q * static_cast<uint32_t>(out_stride);
+      const uint32_t seg = static_cast<uint32_t>(blockIdx.x) * 4 + g, q = 32 * wave + 16 * qh + c;
+      const uint32_t seg_q = seg * kQueriesPerPass + q;
+      // counts are query-major, cnt[q][segment]: the select kernel reads a query's 4 * gridDim counts in one sweep
+      cnt[q * (4u * gridDim.x) + seg] = (off[qh] >> 3) - seg_q * static_cast<uint32_t>(out_stride);
     }
   } else if (active) {
 #pragma unroll
@@ -1108,8 +706,7 @@ using ScanKernel = void (*)(const uint16_t*, int64_t, const uint16_t*, int64_t, 
                             int);
 template <int KS, bool DENSE>
 static ScanKernel scan_kernel() {
-  if constexpr (kShape16) return &mfma_scan_bf16_s16<KS, DENSE>;
-  return &mfma_scan_bf16<KS, DENSE>;
+  return &mfma_scan_bf16_s16<KS, DENSE>;
 }
 
 template <int KS>
@@ -1160,15 +757,18 @@ static hipError_t run_mfma_dim(const MfmaLayout& m, const uint16_t* E, int64_t n
 
 hipError_t launch_prepare_queries_bf16(const float* d_Q, uint16_t* d_out, int n_queries, int n_rows_out, int dim, int space,
                                        float* d_qn2, hipStream_t stream) {
-  hipLaunchKernelGGL(prepare_queries_bf16, dim3(n_rows_out), dim3(kWave), 0, stream, d_Q, d_out, n_queries, dim, space, d_qn2);
+  hipLaunchKernelGGL(prepare_queries_bf16, dim3(n_rows_out), dim3(kWave), 0, stream, d_Q, d_out, n_queries, dim, space, d_qn2, 0);
   return hipGetLastError();
 }
 
 hipError_t launch_mfma_bf16(const MfmaLayout& m, const uint16_t* d_E, int64_t n_rows, int dim, const float* d_Q,
                             int n_queries, int n_candidates, int space, char* ws, int compute_units,
                             hipStream_t stream) {
+  // one launch per group of 256 would index rows from 0: the image of group g starts at g * 256 * dim, and the
+  // fragment order is relative to the group's first query — (q / 32) etc. of the GLOBAL row index differ from the
+  // group-local ones only by whole groups of 256 rows = 256 * dim elements, which is exactly the group's offset
   hipLaunchKernelGGL(prepare_queries_bf16, dim3(m.q_pad), dim3(kWave), 0, stream, d_Q,
-                     reinterpret_cast<uint16_t*>(ws + m.qb_off), n_queries, dim, space, static_cast<float*>(nullptr));
+                     reinterpret_cast<uint16_t*>(ws + m.qb_off), n_queries, dim, space, static_cast<float*>(nullptr), 1);
   switch (dim / 16) {
     case 8: return run_mfma_dim<8>(m, d_E, n_rows, n_queries, n_candidates, ws, compute_units, stream);
     case 16: return run_mfma_dim<16>(m, d_E, n_rows, n_queries, n_candidates, ws, compute_units, stream);

@@ -112,7 +112,7 @@ hipError_t launch_prepare_queries_bf16(const float* d_Q, uint16_t* d_out, int n_
                                        float* d_qn2, hipStream_t stream);
 bool mfma_path_supported(int64_t n_rows, int dim, int n_queries, int n_candidates, int space);
 MfmaLayout plan_mfma(int64_t n_rows, int dim, int n_queries, int n_candidates, int compute_units);
-// Fills cand keys [groups][n_seg][256][seg_cap] and counts [groups][n_seg][256] in the workspace.
+// Fills cand keys [groups][n_seg][256][seg_cap] and counts [groups][256][n_seg] in the workspace.
 hipError_t launch_mfma_bf16(const MfmaLayout& m, const uint16_t* d_E, int64_t n_rows, int dim, const float* d_Q,
                             int n_queries, int n_candidates, int space, char* ws, int compute_units,
                             hipStream_t stream);
@@ -158,15 +158,18 @@ struct RerankParams {
 // sorted candidate records.
 // sorted_lists > 0: the keys are `sorted_lists` lists of n_candidates keys, each sorted descending.
 // d_counts (may be NULL): the keys are per-workgroup SEGMENTS (batched matrix-core scan): segment s of
-// query q holds min(d_counts[s*count_stride + q], cap) keys at d_keys + s*seg_stride + q*cap; a count
+// query q holds min(d_counts[s*count_stride + q*count_query_stride], cap) keys at d_keys + s*seg_stride + q*cap; a count
 // above `cap` marks an overflowed buffer: that query's ids are set to -1, scores to NaN.
 struct SegmentLayout {
   int n_seg;
   int cap;
   int raw;               // 1: entries are raw records (row << 32 | fp32 score bits), not ordered keys
   int64_t seg_stride;    // keys between consecutive segments (= queries_per_pass * cap)
-  int64_t count_stride;  // counts between consecutive segments (= queries_per_pass)
+  int64_t count_stride;  // counts between consecutive segments of one query
   int lds_keys;          // records the select kernel may stage in dynamic LDS (0: read segments in place)
+  int64_t count_query_stride;  // counts between consecutive queries: 1 with count_stride = queries_per_pass (segment-major,
+                               // depth-split pass) or n_seg with count_stride = 1 (query-major: a query's counts are
+                               // contiguous and the select kernel reads them coalesced — the 256-query pass)
 };
 hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, int sorted_lists, int n_queries,
                                 int n_candidates, int k, const RerankParams& rp, const float* d_dewi32, const float* d_ent32,

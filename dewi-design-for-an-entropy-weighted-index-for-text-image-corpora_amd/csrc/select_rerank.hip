@@ -335,7 +335,7 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(
     // Output of the batched matrix-core scan: `seg.n_seg` per-workgroup segments.  A count above the
     // segment capacity means that buffer overflowed and this query was NOT answered: the caller
     // re-runs it on the exact small-batch path (ids = -1 is the documented marker).
-    SegmentKeys kv{keys_all + static_cast<int64_t>(q) * seg.cap, counts + q, seg.seg_stride, seg.count_stride, seg.n_seg,
+    SegmentKeys kv{keys_all + static_cast<int64_t>(q) * seg.cap, counts + q * seg.count_query_stride, seg.seg_stride, seg.count_stride, seg.n_seg,
                    seg.cap, seg.raw != 0};
     extern __shared__ __attribute__((aligned(16))) uint64_t dyn_keys[];
     __shared__ WideRadixShared ws;
