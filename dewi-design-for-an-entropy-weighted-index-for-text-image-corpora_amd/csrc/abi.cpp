@@ -68,13 +68,15 @@ int ensure_device(DeviceInfo& out) {
 thread_local dewi::Tuning g_tuning{0, 0, -1, 1};
 
 // ---- timing ring -----------------------------------------------------------------------------
+// Like the tuning, the measurement state belongs to the CALLING THREAD: dewi_timing_enable / _read and the brackets of
+// the dewi_knn_* calls made from the same host thread share one ring, so two benchmarking threads never mix samples.
 struct Timing {
   int every = 0;          // 0 = off; n = bracket every n-th scan with events
   unsigned long calls = 0;
   std::vector<hipEvent_t> start, stop;
   size_t used = 0;
-} g_timing;
-std::mutex g_timing_mu;
+};
+thread_local Timing g_timing;
 
 // One bracket = two events around the dominant corpus-pass kernel of a call.  begin() decides whether this
 // call is sampled; end() records the stop event of the bracket begin() opened on this thread.
@@ -84,7 +86,6 @@ thread_local hipEvent_t t_open_stop = nullptr;
 
 namespace dewi {
 void timing_begin(hipStream_t stream) {
-  std::lock_guard<std::mutex> lk(g_timing_mu);
   t_open_stop = nullptr;
   if (g_timing.every <= 0) return;
   if ((g_timing.calls++ % static_cast<unsigned long>(g_timing.every)) != 0) return;
@@ -217,7 +218,11 @@ BatchPlan plan_batch(int elem_type, int64_t n_rows, int dim, int n_queries, int 
   BatchPlan P{};
   P.c_local = n_candidates < n_rows ? n_candidates : static_cast<int>(n_rows);
   // the matrix-core paths select exactly n_candidates rows: a shard with fewer rows stays on the row kernels (padding)
-  const bool mfma = g_tuning.mfma != 0 && P.c_local == n_candidates;
+  // space l2 on the matrix cores is scored 2<e,q> - ||e||^2 - ||q||^2: absolute error ~ulp(||e||^2 + ||q||^2), where the
+  // reference's -sum((e - q)^2) (backends.py:434-436) has a small RELATIVE error of the distance — a near-duplicate of the
+  // query would come back as +-1e-4 noise instead of ~0 and search_batch(Q)[j] would differ from search(Q[j]).  Parity
+  // first: l2 batches take the exact row kernels unless the calling thread opted in (dewi_tuning_set batched_mfma = 2).
+  const bool mfma = g_tuning.mfma != 0 && P.c_local == n_candidates && (space == DEWI_SPACE_COSINE || g_tuning.mfma == 2);
   const bool depth_ok = mfma && dewi::mfma_f32_path_supported(elem_type, n_rows, dim, n_queries, n_candidates, space);
   const bool big_ok = mfma && elem_type == 1 && dewi::mfma_path_supported(n_rows, dim, n_queries, n_candidates, space);
   if (depth_ok && (elem_type == 0 || n_queries <= 32 || !big_ok)) {
@@ -601,26 +606,38 @@ int dewi_robust_fit_finish(int64_t n_total, int n_signals, int phase, void* d_wo
   return e == hipSuccess ? DEWI_OK : hip_fail(e, "robust_fit_finish launch");
 }
 
-int dewi_score_f64(const void* d_S, int signals_are_f64, int64_t n, int64_t ld, const double* med, const double* mad,
-                   const double* weights, double delta, int mode, double* d_out, float* d_out32, void* stream) {
-  if (!d_S || !med || !mad || !weights || !d_out) return fail(DEWI_ERR_INVALID_ARG, "null pointer");
+static int score_impl(const void* d_S, int signals_are_f64, int64_t n, int64_t ld, const double* med, const double* mad,
+                      const float* d_med, const float* d_mad, const double* weights, double delta, int mode, double* d_out,
+                      float* d_out32, void* stream) {
+  if (!d_S || !weights || (!d_out && !d_out32)) return fail(DEWI_ERR_INVALID_ARG, "null pointer");
   if (n < 0 || ld < n) return fail(DEWI_ERR_INVALID_ARG, "bad shape n=%lld ld=%lld", static_cast<long long>(n), static_cast<long long>(ld));
   if (mode != DEWI_MODE_STANDARD && mode != DEWI_MODE_CONDITIONAL) return fail(DEWI_ERR_INVALID_ARG, "unknown mode %d", mode);
   if (n == 0) return DEWI_OK;
   dewi::ScoreParams sp;
   for (int s = 0; s < DEWI_NUM_SIGNALS; ++s) {
-    sp.med[s] = med[s];
-    sp.scale[s] = 1.4826 * mad[s];  // reference scorer.py:31 — the product is rounded before the division
+    sp.med[s] = med ? med[s] : 0.0;
+    sp.scale[s] = mad ? 1.4826 * mad[s] : 1.0;  // reference scorer.py:31 — the product is rounded before the division
   }
   for (int i = 0; i < 5; ++i) sp.w[i] = weights[i];
   sp.delta = delta;
   sp.mode = mode;
-  hipError_t e = dewi::launch_score(d_S, signals_are_f64, n, ld, sp, d_out, d_out32, static_cast<hipStream_t>(stream));
+  hipError_t e = dewi::launch_score(d_S, signals_are_f64, n, ld, sp, d_med, d_mad, d_out, d_out32, static_cast<hipStream_t>(stream));
   return e == hipSuccess ? DEWI_OK : hip_fail(e, "score launch");
 }
 
+int dewi_score_f64(const void* d_S, int signals_are_f64, int64_t n, int64_t ld, const double* med, const double* mad,
+                   const double* weights, double delta, int mode, double* d_out, float* d_out32, void* stream) {
+  if (!med || !mad) return fail(DEWI_ERR_INVALID_ARG, "null pointer");
+  return score_impl(d_S, signals_are_f64, n, ld, med, mad, nullptr, nullptr, weights, delta, mode, d_out, d_out32, stream);
+}
+
+int dewi_score_f64_dev(const void* d_S, int signals_are_f64, int64_t n, int64_t ld, const float* d_med, const float* d_mad,
+                       const double* weights, double delta, int mode, double* d_out, float* d_out32, void* stream) {
+  if (!d_med || !d_mad) return fail(DEWI_ERR_INVALID_ARG, "null pointer");
+  return score_impl(d_S, signals_are_f64, n, ld, nullptr, nullptr, d_med, d_mad, weights, delta, mode, d_out, d_out32, stream);
+}
+
 int dewi_timing_enable(int every) {
-  std::lock_guard<std::mutex> lk(g_timing_mu);
   g_timing.every = every > 0 ? every : 0;
   g_timing.calls = 0;
   g_timing.used = 0;
@@ -628,7 +645,6 @@ int dewi_timing_enable(int every) {
 }
 
 int dewi_timing_read(double* out_mean_scan_ms, int* out_launches) {
-  std::lock_guard<std::mutex> lk(g_timing_mu);
   double total = 0.0;
   int n = 0;
   for (size_t i = 0; i < g_timing.used; ++i) {

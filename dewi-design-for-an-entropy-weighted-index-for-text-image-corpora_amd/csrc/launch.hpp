@@ -224,7 +224,8 @@ struct ScoreParams {
   double delta;
   int mode;
 };
-hipError_t launch_score(const void* d_S, int is_f64, int64_t n, int64_t ld, const ScoreParams& sp, double* d_out,
-                        float* d_out32, hipStream_t stream);
+// d_med / d_mad (both or neither): fp32 device statistics that replace sp.med / sp.scale inside the kernel.
+hipError_t launch_score(const void* d_S, int is_f64, int64_t n, int64_t ld, const ScoreParams& sp, const float* d_med,
+                        const float* d_mad, double* d_out, float* d_out32, hipStream_t stream);
 
 }  // namespace dewi

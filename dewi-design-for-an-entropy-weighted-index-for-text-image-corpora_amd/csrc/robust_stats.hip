@@ -310,7 +310,19 @@ hipError_t launch_robust_fit(const float* d_S, int64_t n, int64_t ld, int n_sign
 // ---------------------------------------------------------------------------------------------
 template <class T>
 __global__ __launch_bounds__(256) void score_kernel(const T* __restrict__ S, int64_t n, int64_t ld, ScoreParams sp,
+                                                    const float* __restrict__ d_med, const float* __restrict__ d_mad,
                                                     double* __restrict__ out, float* __restrict__ out32) {
+  if (d_med != nullptr) {
+    // statistics straight from the fit kernels' device output (dewi_score_f64_dev): what the host layer does with
+    // them between fit and score — widen to float64, `mad or 1e-8` (scorer.py:24; -0.0 is falsy too, NaN is not),
+    // 1.4826 * mad rounded once (scorer.py:31) — done here, so nothing has to visit the host in between
+#pragma unroll
+    for (int s = 0; s < DEWI_NUM_SIGNALS; ++s) {
+      const float m = d_mad[s];
+      sp.med[s] = static_cast<double>(d_med[s]);
+      sp.scale[s] = __dmul_rn(1.4826, m == 0.f ? 1e-8 : static_cast<double>(m));
+    }
+  }
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
     double z[DEWI_NUM_SIGNALS];
@@ -337,22 +349,22 @@ __global__ __launch_bounds__(256) void score_kernel(const T* __restrict__ S, int
       U = U > sp.delta ? sp.delta : U;
     }
     const double r = __ddiv_rn(1.0, __dadd_rn(1.0, exp(-U)));              // scorer.py:60-62
-    out[i] = r;
+    if (out) out[i] = r;
     if (out32) out32[i] = static_cast<float>(r);
   }
 }
 
-hipError_t launch_score(const void* d_S, int is_f64, int64_t n, int64_t ld, const ScoreParams& sp, double* d_out,
-                        float* d_out32, hipStream_t stream) {
+hipError_t launch_score(const void* d_S, int is_f64, int64_t n, int64_t ld, const ScoreParams& sp, const float* d_med,
+                        const float* d_mad, double* d_out, float* d_out32, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
   int64_t blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (is_f64)
     hipLaunchKernelGGL(score_kernel<double>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream,
-                       static_cast<const double*>(d_S), n, ld, sp, d_out, d_out32);
+                       static_cast<const double*>(d_S), n, ld, sp, d_med, d_mad, d_out, d_out32);
   else
     hipLaunchKernelGGL(score_kernel<float>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream,
-                       static_cast<const float*>(d_S), n, ld, sp, d_out, d_out32);
+                       static_cast<const float*>(d_S), n, ld, sp, d_med, d_mad, d_out, d_out32);
   return hipGetLastError();
 }
 

@@ -282,7 +282,10 @@ class PipelinedSearcher:
     ``dewi_knn_scan`` / ``dewi_knn_finish`` take the same kernels as the one-call search (a batch of
     queries: the matrix-core passes), so a query of a batch can come back refused (id -1, survivor
     buffer overflowed: adversarial corpora only).  ``drain`` looks at the id output of the last
-    submission into each output buffer and answers such queries again one at a time, in place;
+    submission into each output buffer (an earlier submission into the same buffer has been overwritten anyway) and
+    answers such queries again one at a time, in place, with the shard's ``id_offset`` as ``dewi_knn_finish`` writes
+    it — from the query tensor that was SUBMITTED, which is kept by reference: a caller that reuses one staging buffer
+    for its queries must not overwrite it before ``drain`` (or must submit a clone);
     candidate records (``out_records``) keep their -2 markers for the merge, as
     ``DeviceCorpus.candidates_device``.  The workspace size and the path are fixed from the
     submitting thread's tuning (``_engine.tuning`` is thread-local): construct and submit from one thread.
@@ -364,9 +367,12 @@ class PipelinedSearcher:
                 if out_ids.numel() == 0:
                     continue
                 for j in torch.nonzero(out_ids.view(self.b, -1)[:, 0] < 0).flatten().tolist():   # refused by a matrix-core pass
+                    row_ids = out_ids.view(self.b, -1)[j:j + 1]
                     self.corpus.search_device(q_dev[j:j + 1].contiguous(), self.k, self.eta, self.pref,
-                                              out_ids.view(self.b, -1)[j:j + 1], out_scores.view(self.b, -1)[j:j + 1],
+                                              row_ids, out_scores.view(self.b, -1)[j:j + 1],
                                               candidates=self.c if self._explicit_c else None)
+                    if self.corpus.id_offset:          # dewi_knn_finish wrote the other rows with the shard's id offset;
+                        row_ids += self.corpus.id_offset   # the one-call search answers in local rows
             torch.cuda.current_stream().synchronize()
 
 
@@ -430,6 +436,9 @@ def prepare_queries_bf16(q_dev, space: str = "cosine"):
 
 
 def tuning(scan_blocks: int = 0, rows_per_iter: int = 0, nontemporal: int = -1, batched_mfma: int = 1) -> None:
-    """Launch-shape overrides of the CALLING THREAD (the library keeps them thread-local)."""
+    """Launch-shape overrides of the CALLING THREAD (the library keeps them thread-local).
+    batched_mfma: 0 row kernels only; 1 cosine batches on the matrix cores (default); 2 also ``space="l2"`` batches
+    (2<e,q> - ||e||^2 - ||q||^2: absolute error ~ulp(||e||^2+||q||^2) — near-duplicates of a query lose their
+    near-zero distance; not the parity path)."""
     nat.check(nat.load_library().dewi_tuning_set(int(scan_blocks), int(rows_per_iter), int(nontemporal),
                                                  int(batched_mfma)))

@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = (
     "dewi_row_cosine_f32", "dewi_convert_f32_to_bf16", "dewi_payload_soa_f64", "dewi_knn_workspace_bytes", "dewi_knn_rerank_f32",
     "dewi_knn_rerank_bf16", "dewi_knn_rerank_candidates", "dewi_prepare_queries_bf16", "dewi_knn_scan", "dewi_knn_finish", "dewi_knn_candidates", "dewi_merge_workspace_bytes", "dewi_merge_rerank", "dewi_robust_fit_workspace_bytes",
     "dewi_robust_fit_f32", "dewi_robust_fit_begin", "dewi_robust_fit_hist_f32", "dewi_robust_fit_region",
-    "dewi_robust_fit_pick", "dewi_robust_fit_finish", "dewi_score_f64", "dewi_timing_enable", "dewi_timing_read", "dewi_tuning_set",
+    "dewi_robust_fit_pick", "dewi_robust_fit_finish", "dewi_score_f64", "dewi_score_f64_dev", "dewi_timing_enable", "dewi_timing_read", "dewi_tuning_set",
 )
 
 
@@ -110,6 +110,8 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.dewi_score_f64.restype = i32
     lib.dewi_score_f64.argtypes = [vp, i32, i64, i64, c.POINTER(f64), c.POINTER(f64), c.POINTER(f64), f64, i32, vp,
                                    vp, vp]
+    lib.dewi_score_f64_dev.restype = i32
+    lib.dewi_score_f64_dev.argtypes = [vp, i32, i64, i64, vp, vp, c.POINTER(f64), f64, i32, vp, vp, vp]
     lib.dewi_timing_enable.restype = i32
     lib.dewi_timing_enable.argtypes = [i32]
     lib.dewi_timing_read.restype = i32
@@ -166,6 +168,11 @@ def check(rc: int) -> None:
     if rc == ERR_UNSUPPORTED:
         raise NotImplementedError(msg)
     raise NativeLibraryError(f"dewi_hip error {rc}: {msg}")
+
+
+def is_device_tensor(x) -> bool:
+    """True for a CUDA torch tensor (without importing torch for plain arrays)."""
+    return bool(getattr(x, "is_cuda", False))
 
 
 def stream_ptr() -> int:

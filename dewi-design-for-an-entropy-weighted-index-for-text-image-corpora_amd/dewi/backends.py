@@ -173,7 +173,16 @@ class ExactIndex(BaseIndex):
         ``build`` uploads the columns as they are.  ``Payload`` objects are created lazily — for the
         rows a search returns, or on ``get_payload`` / iteration over ``_payloads`` — and the same
         object is returned from then on.  ``copy=False``: the embedding block is referenced, not
-        copied, until ``build()``; do not modify it in between."""
+        copied, until ``build()``; do not modify it in between.
+
+        DEVICE-RESIDENT ingest: ``embeddings`` may be a CUDA fp32 tensor [m, dim] and the columns CUDA tensors (the
+        ``dewi32`` column of ``DewiScorer.score_batch_device``, signal columns ...).  Nothing is copied to the host;
+        when the block is the whole corpus ``build()`` uses it IN PLACE — cosine rows are normalised inside the
+        caller's tensor (``copy=True`` keeps the caller's tensor intact at the price of a device copy) — and the
+        HBM payload columns are computed on the device from the given columns."""
+        from . import _native as nat
+        if nat.is_device_tensor(embeddings):
+            return self._add_device_block(doc_ids, embeddings, columns, copy)
         emb = np.asarray(embeddings)
         if emb.ndim != 2 or emb.shape[1] != self.dim:
             raise ValueError(f"Expected embeddings of shape (m, {self.dim}), got {emb.shape}")
@@ -187,6 +196,27 @@ class ExactIndex(BaseIndex):
         self._doc_ids.extend(doc_ids)
         self._pending.append(np.array(emb, dtype=np.float32) if copy else np.ascontiguousarray(emb, dtype=np.float32))
         self._pending_rows += emb.shape[0]
+        self._invalidate()
+
+    def _add_device_block(self, doc_ids: Sequence[str], embeddings, columns, copy: bool) -> None:
+        import torch
+        emb = embeddings
+        if emb.dim() != 2 or int(emb.shape[1]) != self.dim:
+            raise ValueError(f"Expected embeddings of shape (m, {self.dim}), got {tuple(emb.shape)}")
+        if len(doc_ids) != int(emb.shape[0]):
+            raise ValueError("doc_ids and embeddings must have the same length")
+        unknown = [name for name in columns if name not in PAYLOAD_FIELDS]
+        if unknown:
+            raise ValueError(f"unknown payload columns {unknown}")
+        if emb.dtype != torch.float32 or not emb.is_contiguous():
+            emb = emb.to(dtype=torch.float32).contiguous()                 # a device copy: no longer the caller's tensor
+        elif copy:
+            emb = emb.clone()
+        row0 = len(self._doc_ids)
+        self._payloads.add_columns(row0, doc_ids, columns)
+        self._doc_ids.extend(doc_ids)
+        self._pending.append(emb)
+        self._pending_rows += int(emb.shape[0])
         self._invalidate()
 
     def _invalidate(self) -> None:
@@ -204,13 +234,76 @@ class ExactIndex(BaseIndex):
         elif self._loaded_rows is not None:
             blocks.append(self._loaded_rows)
             done = self._loaded_rows.shape[0]
-        blocks.extend(b.reshape(-1, self.dim) for b in self._pending)
+        blocks.extend((b.detach().cpu().numpy() if hasattr(b, "is_cuda") else b).reshape(-1, self.dim) for b in self._pending)
         if not blocks:
             return np.empty((0, self.dim), np.float32), 0
         return (blocks[0] if len(blocks) == 1 else np.concatenate(blocks, axis=0)), done
 
+    def _build_device(self) -> None:
+        """``build`` when device-resident blocks are pending: the matrix is assembled (or, for one block that is the
+        whole corpus, simply taken) on the GPU, new rows are normalised there, and the two fp32 payload columns the
+        re-rank reads are computed on the device.  No row and no column visits the host."""
+        import torch
+        from . import _native as nat
+        from ._engine import DeviceCorpus
+        lib = nat.load_library()
+        n = len(self._doc_ids)
+        dev_blocks = [b for b in self._pending if hasattr(b, "is_cuda")]
+        dev = dev_blocks[0].device
+        stored = None
+        if self._corpus is not None:
+            stored = self._corpus.emb.float() if self._corpus.is_bf16 else self._corpus.emb
+        elif self._loaded_rows is not None:
+            stored = torch.from_numpy(self._loaded_rows).to(dev)
+        already = 0 if stored is None else int(stored.shape[0])
+        with torch.cuda.device(dev):
+            if stored is None and len(self._pending) == 1 and int(dev_blocks[0].shape[0]) == n:
+                emb = dev_blocks[0]                                        # the caller's tensor, in place
+            else:
+                emb = torch.empty((n, self.dim), dtype=torch.float32, device=dev)
+                at = 0
+                if stored is not None:
+                    emb[:already].copy_(stored)
+                    at = already
+                for b in self._pending:
+                    blk = b if hasattr(b, "is_cuda") else torch.from_numpy(np.ascontiguousarray(b.reshape(-1, self.dim), dtype=np.float32))
+                    emb[at:at + int(blk.shape[0])].copy_(blk)
+                    at += int(blk.shape[0])
+                if at != n:
+                    raise ValueError(f"{n} doc ids but {at} embedding rows")
+            if self._normalize and already < n:
+                tail = emb[already:]
+                nat.check(lib.dewi_normalize_rows_f32(nat.ptr(tail), nat.ptr(tail), n - already, self.dim, nat.stream_ptr()))
+            # payload columns: device blocks contribute on the device; rows that came with host data through the host
+            fields = ("dewi", "ht_mean", "hi_mean")
+            blocks = list(self._payloads.column_blocks())
+            covered = sum(r1 - r0 for r0, r1, cols, made in blocks
+                          if any(hasattr(c, "is_cuda") for c in cols.values()) and not made)
+            if covered == n:
+                c64 = {}
+                for name in fields:
+                    parts = [(cols[name].to(device=dev, dtype=torch.float64) if name in cols
+                              else torch.zeros(r1 - r0, dtype=torch.float64, device=dev)) for r0, r1, cols, _ in blocks]
+                    c64[name] = (parts[0] if len(parts) == 1 else torch.cat(parts)).contiguous()
+            else:
+                host = self._payload_columns()
+                c64 = {name: torch.from_numpy(host[name]).to(dev) for name in fields}
+            dewi32 = torch.empty(n, dtype=torch.float32, device=dev)
+            ent32 = torch.empty(n, dtype=torch.float32, device=dev)
+            nat.check(lib.dewi_payload_soa_f64(nat.ptr(c64["dewi"]), nat.ptr(c64["ht_mean"]), nat.ptr(c64["hi_mean"]),
+                                               nat.ptr(dewi32), nat.ptr(ent32), n, nat.stream_ptr()))
+            torch.cuda.current_stream().synchronize()
+        self._corpus = DeviceCorpus(emb, dewi32, ent32, self.space)
+        self._pending = []
+        self._pending_rows = 0
+        self._loaded_rows = None
+        self._host_rows = None
+        self._is_trained = True
+
     def build(self, **kwargs: Any) -> None:
         from ._engine import DeviceCorpus
+        if any(hasattr(b, "is_cuda") for b in self._pending):
+            return self._build_device()
         rows, already = self._raw_matrix()
         if rows.shape[0] == 0:
             raise ValueError("No embeddings to build index from")
@@ -253,7 +346,8 @@ class ExactIndex(BaseIndex):
         for row0, row1, cols, made in store.column_blocks():
             for name in fields:
                 if name in cols:
-                    out[name][row0:row1] = cols[name]
+                    c = cols[name]
+                    out[name][row0:row1] = c.detach().cpu().numpy() if hasattr(c, "is_cuda") else c
             for row, p in made.items():
                 for name in fields:
                     out[name][row] = getattr(p, name)
@@ -343,6 +437,7 @@ class ExactIndex(BaseIndex):
     def results_for(self, rows: np.ndarray, scores: np.ndarray) -> List[SearchResult]:
         """Row indices/scores of ``search_batch`` -> the reference's (doc_id, score, Payload) tuples."""
         ids, at_row = self._doc_ids, self._payloads.at_row
+        self._payloads.ensure_rows(np.unique(np.asarray(rows)).tolist(), ids)      # device-resident payload columns: one gather
         return [[(ids[r], float(s), at_row(r, ids[r])) for r, s in zip(rr.tolist(), ss.tolist())]
                 for rr, ss in zip(rows, scores)]
 

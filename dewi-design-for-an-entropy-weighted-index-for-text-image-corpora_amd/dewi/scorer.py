@@ -22,9 +22,56 @@ from . import _native as nat
 from .types import SIGNAL_FIELDS, Weights
 
 
+def _device_table(columns: Mapping[str, "torch.Tensor"], keys: Sequence[str]):  # noqa: F821
+    """CUDA columns -> (table tensor whose rows are the columns, n, leading dimension in elements).  Columns that are
+    already the consecutive rows of ONE contiguous fp32 [n_signals][ld] tensor (views of a signal table) are used in
+    place — no copy of anything n long; anything else is stacked on the device."""
+    import torch
+    cols = [columns[k] for k in keys]
+    n = int(cols[0].shape[0])
+    if any(c.dim() != 1 or int(c.shape[0]) != n for c in cols):
+        raise ValueError("signal columns must be 1-D tensors of one length")
+    same = all(c.dtype == torch.float32 and c.is_contiguous() and c.device == cols[0].device for c in cols)
+    if same and n > 0:
+        step = (cols[1].data_ptr() - cols[0].data_ptr()) // 4 if len(cols) > 1 else n
+        in_place = step >= n and all(c.data_ptr() == cols[0].data_ptr() + 4 * step * j for j, c in enumerate(cols))
+        if in_place and cols[0].untyped_storage().data_ptr() == cols[-1].untyped_storage().data_ptr():
+            return cols[0], n, int(step)            # nat.ptr(cols[0]) is the table's first element
+    table = torch.stack([c.to(dtype=torch.float32) for c in cols]).contiguous()
+    return table, n, n
+
+
+def _fit_columns_device(columns: Mapping[str, "torch.Tensor"]):  # noqa: F821
+    """CUDA fp32 columns -> (keys, fp32 device medians, fp32 device MADs): nothing n long leaves the device and nothing
+    is synchronised (``dewi_robust_fit_f32`` on the current stream)."""
+    import torch
+    lib = nat.load_library()
+    keys = list(columns.keys())
+    table, n, ld = _device_table(columns, keys)
+    if n == 0:
+        raise IndexError("cannot fit robust statistics on an empty table")
+    with torch.cuda.device(table.device):
+        med = torch.empty(len(keys), dtype=torch.float32, device=table.device)
+        mad = torch.empty(len(keys), dtype=torch.float32, device=table.device)
+        ws_bytes = int(lib.dewi_robust_fit_workspace_bytes(len(keys)))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=table.device)
+        nat.check(lib.dewi_robust_fit_f32(nat.ptr(table), n, ld, len(keys), nat.ptr(med), nat.ptr(mad), nat.ptr(ws), ws_bytes,
+                                          nat.stream_ptr()))
+    return keys, med, mad
+
+
+def _stats_to_host(keys, med, mad) -> (Dict[str, float], Dict[str, float]):
+    med_h = med.cpu().numpy().astype(np.float64)
+    mad_h = mad.cpu().numpy().astype(np.float64)
+    return ({k: float(med_h[j]) for j, k in enumerate(keys)},
+            {k: float(mad_h[j]) or 1e-8 for j, k in enumerate(keys)})       # scorer.py:24
+
+
 def _fit_columns(columns: Mapping[str, np.ndarray]) -> (Dict[str, float], Dict[str, float]):
     """fp32 columns -> (medians, MADs) through ``dewi_robust_fit_f32``."""
     import torch
+    if columns and all(nat.is_device_tensor(c) for c in columns.values()):
+        return _stats_to_host(*_fit_columns_device(columns))
     lib = nat.load_library()
     keys = list(columns.keys())
     n = len(columns[keys[0]])
@@ -93,13 +140,28 @@ class DewiScorer:
     def __init__(self, weights: Optional[Weights] = None, delta: float = 3.0):
         self.weights = weights or Weights()
         self.weights.delta = delta
-        self.stats: Optional[RobustStats] = None
+        self._stats: Optional[RobustStats] = None
+        self._stats_dev = None        # (keys, fp32 medians, fp32 MADs) on the device, from a device-resident fit
         # Row API acceleration (see score()): the table fit_stats() saw, and its scores per mode.
         self._table_rows: Optional[List[Dict[str, float]]] = None
         self._table_cols: Optional[Dict[str, np.ndarray]] = None
         self._table_scores: Dict[tuple, np.ndarray] = {}
         self._table_pos: Optional[Dict[int, int]] = None
+        self._table_len = 0
         self._cursor = 0
+
+    # ``stats`` is the reference's attribute (scorer.py:39, :45-46).  After a device-resident fit the numbers are still
+    # on the GPU: they are brought over (seven floats) the first time somebody looks at them.
+    @property
+    def stats(self) -> Optional[RobustStats]:
+        if self._stats is None and self._stats_dev is not None:
+            self._stats = RobustStats(*_stats_to_host(*self._stats_dev))
+        return self._stats
+
+    @stats.setter
+    def stats(self, value: Optional[RobustStats]) -> None:
+        self._stats = value
+        self._stats_dev = None
 
     # -- fitting ---------------------------------------------------------------------
     def fit_stats(self, rows: List[Dict[str, float]]) -> None:
@@ -112,6 +174,7 @@ class DewiScorer:
         # whole table in one kernel launch and the row API serves from that column.
         self._table_rows = rows if all(k in cols for k in SIGNAL_FIELDS) else None
         self._table_cols = cols if self._table_rows is not None else None
+        self._table_len = len(rows)           # the caller may grow its list afterwards: only these rows were scored
         self._table_scores = {}
         self._table_pos = None
         self._cursor = 0
@@ -122,7 +185,14 @@ class DewiScorer:
         self._cursor = 0
 
     def fit_stats_columns(self, columns: Mapping[str, np.ndarray]) -> None:
-        self.stats = RobustStats.fit_columns(columns)
+        """Bulk ``fit_stats``: one array per signal.  CUDA tensors (fp32; ideally the rows of one [7][N] table, which is
+        then read in place) are fitted where they are: the call only enqueues two kernels, the medians / MADs stay on
+        the device for ``score_batch_device`` and reach the host when ``.stats`` is read."""
+        if columns and all(nat.is_device_tensor(c) for c in columns.values()):
+            self._stats = None
+            self._stats_dev = _fit_columns_device(columns)
+        else:
+            self.stats = RobustStats.fit_columns(columns)
         self._forget_table()
 
     def fit_stats_sharded(self, local_columns: Mapping[str, np.ndarray], group=None) -> None:
@@ -131,12 +201,54 @@ class DewiScorer:
         self._forget_table()
 
     def is_fitted(self) -> bool:
-        return self.stats is not None
+        return self._stats is not None or self._stats_dev is not None
 
     # -- scoring ---------------------------------------------------------------------
+    def score_batch_device(self, columns: Mapping[str, "torch.Tensor"], mode: str = "standard",  # noqa: F821
+                           want_f64: bool = True, want_dewi32: bool = True):
+        """``score_batch`` on CUDA columns, results left on the device: (float64 scores or None, fp32 scores or None).
+        The fp32 column is what ``ExactIndex.add_batch_columns(..., {"dewi": ...})`` takes as it is.  After a
+        device-resident ``fit_stats_columns`` the statistics are read by the kernel from where the fit left them
+        (``dewi_score_f64_dev``): fit -> score -> index build is one stream of kernels, no host round trip."""
+        import torch
+        assert self.is_fitted(), "Call fit_stats() before scoring."
+        if mode not in nat.MODE_CODES:
+            raise ValueError(f"unknown mode {mode!r}")
+        if not (want_f64 or want_dewi32):
+            raise ValueError("nothing to compute")
+        lib = nat.load_library()
+        cols = {k: columns[k] for k in SIGNAL_FIELDS}                 # KeyError on a missing signal
+        if not all(nat.is_device_tensor(c) for c in cols.values()):
+            raise TypeError("score_batch_device takes CUDA tensors (use score_batch for host arrays)")
+        if any(c.dtype == torch.float64 for c in cols.values()):
+            table = torch.stack([c.to(dtype=torch.float64) for c in cols.values()]).contiguous()
+            n, ld, as_f64 = int(table.shape[1]), int(table.shape[1]), 1
+        else:
+            table, n, ld = _device_table(cols, SIGNAL_FIELDS)
+            as_f64 = 0
+        w = (ctypes.c_double * 5)(*self.weights.as_vector().tolist())
+        with torch.cuda.device(table.device):
+            out = torch.empty(n, dtype=torch.float64, device=table.device) if want_f64 else None
+            out32 = torch.empty(n, dtype=torch.float32, device=table.device) if want_dewi32 else None
+            dev = self._stats_dev
+            if dev is not None and self._stats is None and list(dev[0]) == list(SIGNAL_FIELDS):
+                nat.check(lib.dewi_score_f64_dev(nat.ptr(table), as_f64, n, ld, nat.ptr(dev[1]), nat.ptr(dev[2]), w,
+                                                 float(self.weights.delta), nat.MODE_CODES[mode], nat.ptr(out),
+                                                 nat.ptr(out32), nat.stream_ptr()))
+            else:
+                arr = ctypes.c_double * len(SIGNAL_FIELDS)
+                med = arr(*[self.stats.medians[k] for k in SIGNAL_FIELDS])
+                mad = arr(*[self.stats.mads[k] for k in SIGNAL_FIELDS])
+                nat.check(lib.dewi_score_f64(nat.ptr(table), as_f64, n, ld, med, mad, w, float(self.weights.delta),
+                                             nat.MODE_CODES[mode], nat.ptr(out), nat.ptr(out32), nat.stream_ptr()))
+        return out, out32
+
     def _run(self, columns: Mapping[str, Sequence[float]], mode: str, want32: bool = False):
         import torch
         assert self.stats is not None, "Call fit_stats() before scoring."
+        if all(nat.is_device_tensor(columns[k]) for k in SIGNAL_FIELDS):       # KeyError on a missing signal
+            out, out32 = self.score_batch_device(columns, mode, True, want32)
+            return (out.cpu().numpy(), out32.cpu().numpy()) if want32 else out.cpu().numpy()
         lib = nat.load_library()
         cols = [np.atleast_1d(np.asarray(columns[k])) for k in SIGNAL_FIELDS]      # KeyError on a missing signal
         n = cols[0].shape[0]
@@ -164,18 +276,18 @@ class DewiScorer:
         rows, cols = self._table_rows, self._table_cols
         if rows is None:
             return None
-        n = len(rows)
+        n = min(self._table_len, len(rows))                  # rows appended after fit_stats() are not in the table
         i = self._cursor
         if not (i < n and rows[i] is sig):
             if self._table_pos is None:
-                self._table_pos = {id(r): j for j, r in enumerate(rows)}
+                self._table_pos = {id(r): j for j, r in enumerate(rows[:n])}
             i = self._table_pos.get(id(sig), -1)
-            if i < 0 or rows[i] is not sig:
+            if i < 0 or i >= n or rows[i] is not sig:
                 return None
         try:
             if any(sig[k] != cols[k][i] for k in SIGNAL_FIELDS):
                 return None                                   # edited since fit_stats(): score it afresh
-        except KeyError:
+        except (KeyError, IndexError):
             return None
         key = (mode, tuple(self.weights.as_vector().tolist()), float(self.weights.delta),
                tuple(self.stats.medians[k] for k in SIGNAL_FIELDS), tuple(self.stats.mads[k] for k in SIGNAL_FIELDS))
@@ -203,6 +315,7 @@ class DewiScorer:
 
         float32 columns stay float32 on the device (7 x 4 B per document); any other dtype is
         uploaded as float64 so that ``z`` sees exactly the caller's value, as in the reference.
+        CUDA tensors are scored where they are (``score_batch_device`` keeps the result there too).
         """
         if mode not in nat.MODE_CODES:
             raise ValueError(f"unknown mode {mode!r}")

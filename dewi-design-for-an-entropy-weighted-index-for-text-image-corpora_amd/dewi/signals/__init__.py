@@ -29,48 +29,76 @@ RedundancyEstimator = None
 NoiseEstimator = None
 
 
-def cross_modal_similarity(text_emb, image_emb) -> np.ndarray:
-    """``I_hat[i] = cos(text_emb[i], image_emb[i])`` for [N, d] fp32 arrays (host or CUDA tensors)."""
+def cross_modal_similarity(text_emb, image_emb, return_device: bool = False, out=None):
+    """``I_hat[i] = cos(text_emb[i], image_emb[i])`` for [N, d] fp32 arrays (host or CUDA tensors).
+    ``return_device=True``: the fp32 [N] result stays on the GPU (a CUDA tensor, nothing synchronised) — ready to be a
+    row of the signal table ``DewiScorer.fit_stats_columns`` / ``score_batch_device`` read in place; ``out`` (a CUDA
+    fp32 [N] tensor, e.g. that row itself) receives the result instead of a fresh tensor."""
     import torch
     lib = nat.load_library()
     a = text_emb if isinstance(text_emb, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(text_emb, dtype=np.float32))
     b = image_emb if isinstance(image_emb, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(image_emb, dtype=np.float32))
     if a.shape != b.shape or a.dim() != 2:
         raise ValueError(f"expected two [N, d] arrays of the same shape, got {tuple(a.shape)} and {tuple(b.shape)}")
-    a = a.to(device="cuda", dtype=torch.float32).contiguous()
-    b = b.to(device="cuda", dtype=torch.float32).contiguous()
-    out = torch.empty(a.shape[0], dtype=torch.float32, device=a.device)
-    nat.check(lib.dewi_row_cosine_f32(nat.ptr(a), nat.ptr(b), nat.ptr(out), a.shape[0], a.shape[1], nat.stream_ptr()))
-    return out.cpu().numpy()
+    dev = a.device if a.is_cuda else (b.device if b.is_cuda else torch.device("cuda", torch.cuda.current_device()))
+    a = a.to(device=dev, dtype=torch.float32).contiguous()
+    b = b.to(device=dev, dtype=torch.float32).contiguous()
+    with torch.cuda.device(dev):
+        if out is None:
+            out = torch.empty(a.shape[0], dtype=torch.float32, device=dev)
+        elif not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (a.shape[0],)):
+            raise ValueError("out must be a contiguous CUDA fp32 tensor of N elements")
+        nat.check(lib.dewi_row_cosine_f32(nat.ptr(a), nat.ptr(b), nat.ptr(out), a.shape[0], a.shape[1], nat.stream_ptr()))
+    return out if return_device else out.cpu().numpy()
 
 
-def redundancy_top1(text_emb: np.ndarray, image_emb: np.ndarray, batch: int = 1024, bf16: Optional[bool] = None
-                    ) -> np.ndarray:
+def redundancy_top1(text_emb, image_emb, batch: int = 1024, bf16: Optional[bool] = None, return_device: bool = False):
     """Highest cosine similarity between document i's text and the image of any other document.
 
     Self-join through the kNN kernels: the normalised image embeddings are the corpus, the text
     embeddings the queries, k = 2 (the best match that is not the document itself).  ``bf16``
     (default: for 64K+ rows) stores the corpus in bf16 and uses the batched matrix-core path.
+    Host arrays or CUDA tensors; ``return_device=True`` leaves the fp32 [N] result on the GPU.
     """
+    import torch
     from .._engine import DeviceCorpus
-    t = np.ascontiguousarray(text_emb, dtype=np.float32)
-    im = np.ascontiguousarray(image_emb, dtype=np.float32)
-    if t.shape != im.shape or t.ndim != 2:
-        raise ValueError(f"expected two [N, d] arrays of the same shape, got {t.shape} and {im.shape}")
-    n = t.shape[0]
+    on_dev = nat.is_device_tensor(text_emb) and nat.is_device_tensor(image_emb)
+    if on_dev:
+        t_dev = text_emb.to(dtype=torch.float32).contiguous()
+        if tuple(text_emb.shape) != tuple(image_emb.shape) or text_emb.dim() != 2:
+            raise ValueError(f"expected two [N, d] arrays of the same shape, got {tuple(text_emb.shape)} and {tuple(image_emb.shape)}")
+        n = int(t_dev.shape[0])
+        t = None
+    else:
+        t = np.ascontiguousarray(text_emb.cpu().numpy() if hasattr(text_emb, "cpu") else text_emb, dtype=np.float32)
+        im = np.ascontiguousarray(image_emb.cpu().numpy() if hasattr(image_emb, "cpu") else image_emb, dtype=np.float32)
+        if t.shape != im.shape or t.ndim != 2:
+            raise ValueError(f"expected two [N, d] arrays of the same shape, got {t.shape} and {im.shape}")
+        n = t.shape[0]
     if n < 2:
-        return np.zeros(n, np.float32)
-    zeros = np.zeros(n)
-    corpus = DeviceCorpus.from_host(im, zeros, zeros, zeros, "cosine")
+        z = np.zeros(n, np.float32)
+        return torch.from_numpy(z).cuda() if return_device else z
+    if on_dev:
+        lib = nat.load_library()
+        emb = image_emb.to(dtype=torch.float32).contiguous().clone()      # the corpus: a normalised copy, on the device
+        with torch.cuda.device(emb.device):
+            nat.check(lib.dewi_normalize_rows_f32(nat.ptr(emb), nat.ptr(emb), n, int(emb.shape[1]), nat.stream_ptr()))
+        zero = torch.zeros(n, dtype=torch.float32, device=emb.device)
+        corpus = DeviceCorpus(emb, zero, zero, "cosine")
+    else:
+        zeros = np.zeros(n)
+        corpus = DeviceCorpus.from_host(im, zeros, zeros, zeros, "cosine")
     if bf16 is None:
         bf16 = n >= 65536
     if bf16:
         corpus = corpus.to_bf16()
+        if on_dev:
+            del emb
     # Queries and results stay on the device: batches are enqueued back to back without a host round trip
     # (1 M x 512: the 977 batches are then bound by the matrix-core scans, ~1 PFLOP of them).
-    import torch
     dev = corpus.device
-    t_dev = torch.from_numpy(t).to(dev)
+    if not on_dev:
+        t_dev = torch.from_numpy(t).to(dev)
     out_dev = torch.empty(n, dtype=torch.float32, device=dev)
     bad_dev = torch.zeros(n, dtype=torch.bool, device=dev)
     rows = torch.arange(n, device=dev)
@@ -80,11 +108,10 @@ def redundancy_top1(text_emb: np.ndarray, image_emb: np.ndarray, batch: int = 10
         own = ids[:, 0] == rows[s:e]
         out_dev[s:e] = torch.where(own, sims[:, 1], sims[:, 0])
         bad_dev[s:e] = ids[:, 0] < 0                                   # batched bf16 path overflowed for that query
-    out = out_dev.cpu().numpy()
-    for i in np.nonzero(bad_dev.cpu().numpy())[0]:                     # adversarial corpora only: exact re-run
-        ids, sims = corpus.search(t[i:i + 1], k=2, eta=0.0, entropy_pref=0.0)
-        out[i] = sims[0, 1] if ids[0, 0] == i else sims[0, 0]
-    return out
+    for i in torch.nonzero(bad_dev).flatten().tolist():               # adversarial corpora only: exact re-run
+        ids, sims = corpus.search_device(t_dev[i:i + 1].contiguous(), 2, 0.0, 0.0)
+        out_dev[i] = torch.where(ids[0, 0] == i, sims[0, 1], sims[0, 0])
+    return out_dev if return_device else out_dev.cpu().numpy()
 
 
 __all__ = ["TextEntropyEstimator", "ImageEntropyEstimator", "CrossModalDependency", "RedundancyEstimator",

@@ -104,11 +104,16 @@ class PayloadStore(dict):
 
     # ---- ingest -----------------------------------------------------------------------------
     def add_columns(self, row0: int, doc_ids: Sequence[str], columns: Mapping[str, np.ndarray]) -> None:
-        cols = {name: np.asarray(columns[name], dtype=np.float64) for name in PAYLOAD_FIELDS if name in columns}
+        """``columns[name]``: a host array, or a CUDA tensor that STAYS on the device (``ExactIndex`` builds its HBM
+        columns from it there); ``Payload`` objects of such a block are made from the handful of rows a search
+        returns (one gather + one small copy, ``ensure_rows``) — only whole-store views (iteration, ``save``) bring a
+        device block to the host."""
+        cols = {name: (columns[name] if getattr(columns[name], "is_cuda", False) else np.asarray(columns[name], dtype=np.float64))
+                for name in PAYLOAD_FIELDS if name in columns}
         n = len(doc_ids)
         for name, c in cols.items():
-            if c.shape != (n,):
-                raise ValueError(f"payload column {name!r} has shape {c.shape}, expected ({n},)")
+            if tuple(c.shape) != (n,):
+                raise ValueError(f"payload column {name!r} has shape {tuple(c.shape)}, expected ({n},)")
         self._starts.append(int(row0))
         self._blocks.append((int(row0), int(row0) + n, doc_ids, cols))
         self._made.append({})
@@ -130,6 +135,41 @@ class PayloadStore(dict):
         if j < 0:
             raise KeyError(doc_id)
         return self._make(j, row, doc_id)
+
+    def _block_on_device(self, j: int) -> bool:
+        return any(getattr(c, "is_cuda", False) for c in self._blocks[j][3].values())
+
+    def _block_to_host(self, j: int) -> None:
+        row0, row1, ids, cols = self._blocks[j]
+        self._blocks[j] = (row0, row1, ids, {name: (c.detach().cpu().numpy().astype(np.float64) if getattr(c, "is_cuda", False) else c)
+                                             for name, c in cols.items()})
+
+    def ensure_rows(self, rows: Sequence[int], doc_ids: Sequence[str]) -> None:
+        """Make the ``Payload`` objects of ``rows`` that live in device-resident column blocks: per block ONE gather
+        of the wanted rows over all its columns and one small device-to-host copy."""
+        want: Dict[int, List[int]] = {}
+        for row in rows:
+            if dict.__contains__(self, doc_ids[row]):
+                continue
+            j = self._block_of(row)
+            if j >= 0 and row not in self._made[j] and self._block_on_device(j):
+                want.setdefault(j, []).append(row)
+        if not want:
+            return
+        import torch
+        for j, rws in want.items():
+            row0, _, _, cols = self._blocks[j]
+            rws = sorted(set(rws))
+            names = list(cols)
+            dev = next(c.device for c in cols.values() if getattr(c, "is_cuda", False))
+            idx = torch.tensor([r - row0 for r in rws], dtype=torch.int64, device=dev)
+            block = torch.stack([(c if getattr(c, "is_cuda", False) else torch.from_numpy(c).to(dev)).index_select(0, idx).double()
+                                 for c in cols.values()]).cpu().numpy()
+            for t, row in enumerate(rws):
+                p = Payload(**{name: float(block[f, t]) for f, name in enumerate(names)})
+                dict.__setitem__(self, doc_ids[row], p)
+                self._made[j][row] = p
+                self._lazy_count -= 1
 
     def _make(self, j: int, row: int, doc_id: str) -> "Payload":
         row0, _, _, cols = self._blocks[j]
@@ -173,6 +213,9 @@ class PayloadStore(dict):
 
     def materialize_all(self) -> None:
         if self._lazy_count:
+            for j in range(len(self._blocks)):
+                if self._block_on_device(j):
+                    self._block_to_host(j)        # a whole-store view: the block's columns come over once
             for j, (row0, _, ids, _) in enumerate(self._blocks):
                 made = self._made[j]
                 for i, doc_id in enumerate(ids):

@@ -237,24 +237,38 @@ int dewi_robust_fit_finish(int64_t n_total, int n_signals, int phase, void* d_wo
  * d_S: DEWI_NUM_SIGNALS columns (fixed order above), column s at element offset s*ld, of fp32
  * (signals_are_f64 = 0) or float64 (= 1) values.  med/mad/weights are HOST arrays
  * (7, 7 and 5 doubles: alpha_t, alpha_i, alpha_m, alpha_r, alpha_n).  d_out: n float64 values;
- * d_out32 (may be NULL): the same rounded to fp32, ready to be the index's dewi32 column.
+ * d_out32: the same rounded to fp32, ready to be the index's dewi32 column (either may be NULL, not both).
  * ------------------------------------------------------------------------------------------ */
 int dewi_score_f64(const void* d_S, int signals_are_f64, int64_t n, int64_t ld, const double* med,
                    const double* mad, const double* weights, double delta, int mode, double* d_out,
                    float* d_out32, void* stream);
+
+/* The same score with the statistics read from DEVICE memory: d_med / d_mad are the fp32 [DEWI_NUM_SIGNALS]
+ * outputs of dewi_robust_fit_f32 (or of the sharded fit) as they are.  What the host does between fit and
+ * score in the reference — widening to float64 and the `mad or 1e-8` substitution of scorer.py:24 — happens
+ * inside the kernel, bit for bit, so a fit -> score -> index-build chain (reference pipelines.py:180-223) runs
+ * on one stream without a host round trip.  (ABI 4.) */
+int dewi_score_f64_dev(const void* d_S, int signals_are_f64, int64_t n, int64_t ld, const float* d_med,
+                       const float* d_mad, const double* weights, double delta, int mode, double* d_out,
+                       float* d_out32, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py): dewi_timing_enable(n) makes every n-th dewi_knn_* call bracket its
  * corpus-scan kernel with hipEvents on `stream` (n = 1: every call; 0: off — the two event records
  * cost ~5 us of stream time, so throughput runs sample); dewi_timing_read synchronises those
  * events and returns the mean scan-kernel duration in milliseconds and the number of launches
- * averaged, then resets.
+ * averaged, then resets.  The state belongs to the CALLING THREAD (thread-local, like dewi_tuning_set): a
+ * thread's brackets, its enable and its read go together, two measuring threads never mix samples.
  * ------------------------------------------------------------------------------------------ */
 int dewi_timing_enable(int every);
 int dewi_timing_read(double* out_mean_scan_ms, int* out_launches);
 
 /* Launch-shape overrides for tuning sweeps (0 / -1 = planner default).  batched_mfma = 0 disables the
- * matrix-core paths (every batch then takes the small-batch scan kernels).  The setting belongs to the
+ * matrix-core paths (every batch then takes the small-batch scan kernels); 1 (default) = cosine batches on the
+ * matrix cores, l2 batches on the exact row kernels; 2 = l2 batches on the matrix cores as well, scored as
+ * 2<e,q> - ||e||^2 - ||q||^2, whose ABSOLUTE error is ~ulp(||e||^2 + ||q||^2) where the reference's
+ * -sum((e-q)^2) (backends.py:434-436) has a relative error of the distance: near-duplicates of a query then score
+ * +-1e-4 instead of ~0 at ||e||^2 ~ 500 (an opt-in for throughput, not the parity path).  The setting belongs to the
  * CALLING THREAD (thread-local): it changes the plan, and with it dewi_knn_workspace_bytes, only for calls
  * made from the same thread, so one thread's sweep cannot invalidate another thread's workspace. */
 int dewi_tuning_set(int scan_blocks, int rows_per_iter, int nontemporal, int batched_mfma);

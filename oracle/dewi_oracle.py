@@ -222,8 +222,13 @@ def ann_library_distance(E: np.ndarray, q_prepared: np.ndarray, space: str = "co
 def ann_similarity(dist: np.ndarray, kind: str) -> np.ndarray:
     """Neighbour distance -> the similarity the reference blends.  ``one_minus_dist``: backends.py:229-231
     ``(1 - dist)`` (HNSWIndex); ``inv_one_plus_dist``: backends.py:337-338 ``1.0 / (1.0 + dist)`` (FAISSIndex
-    with METRIC_L2).  ``dist`` is an fp32 scalar in the reference; under NumPy >= 2 (NEP 50) Python scalars are
-    weak, so both expressions stay fp32."""
+    with METRIC_L2).  ``dist`` is an np.float32 SCALAR in the reference and ``payload.dewi`` / ``eta`` are Python
+    floats.  The reference pins numpy<2.0 (pyproject.toml:39): there value-based casting makes ``1.0/(1.0+dist)``,
+    ``(1-eta)*(1-dist)`` and ``eta*payload.dewi`` float64 scalar arithmetic (backends.py:229-231, 337-346); under
+    NumPy >= 2 (NEP 50, what this container runs) the same expressions stay fp32.  This restatement and the device blend
+    (csrc/select_rerank.hip ``blend``) are the fp32 form, one rounding per operation, on the fp32 ``dewi32`` column:
+    against the numpy<2 float64 form that is a deliberate deviation of at most ~1e-7 relative in the adjusted score
+    (well inside north_star's 1e-5).  Parity of A10 is unpinned either way: hnswlib / faiss are not importable."""
     d = np.asarray(dist, dtype=np.float32)
     if kind == "one_minus_dist":
         return (np.float32(1.0) - d).astype(np.float32)

@@ -22,6 +22,19 @@ import dewi_oracle as orc
 from parity import check_batch, device_prepared_queries
 
 pytestmark = pytest.mark.gpu
+
+# space="l2" on the matrix cores is opt-in (dewi_tuning_set batched_mfma = 2: its score 2<e,q> - ||e||^2 - ||q||^2 has an
+# absolute error of ~ulp(||e||^2 + ||q||^2); by default l2 batches take the exact row kernels, tests/test_hip_round3.py).
+# This module tests the matrix-core passes themselves, in both spaces: every test runs opted in.
+MFMA_ON = 2
+
+
+@pytest.fixture(autouse=True)
+def _l2_on_the_matrix_cores():
+    from dewi import _engine as eng
+    eng.tuning(0, 0, -1, MFMA_ON)
+    yield
+    eng.tuning(0, 0, -1, 1)
 TOL = dict(gap=1e-6, score_tol=1e-5, prepared=True, exact_gaps=False)
 
 
@@ -55,7 +68,7 @@ def test_mfma_batched_vs_oracle(dim, n, b, k):
     try:
         ids_s = np.concatenate([cb.search(Q[i:i + 4], k, 0.3, 0.1)[0] for i in range(0, min(b, 32), 4)])
     finally:
-        eng.tuning(0, 0, -1, 1)
+        eng.tuning(0, 0, -1, MFMA_ON)
     agree = np.mean(ids_s == ids[: ids_s.shape[0]])
     assert agree > 0.98, agree          # the two paths sum in different orders: rare near-tie swaps only
 

@@ -4,6 +4,8 @@
   shard (dewi_knn_candidates / dewi_knn_scan + dewi_knn_finish sort in the workspace) and merges of more than
   2048 records per query (dewi_merge_rerank rank-merges the sorted shard lists through a workspace) — the
   reference has no such limit (backends.py:439-471);
+* space="l2" batches keep the reference's arithmetic by default (the matrix-core form 2<e,q> - ||e||^2 - ||q||^2 is an
+  opt-in): near-duplicate queries at large norms, unscaled 1e-5 tolerance, batch == single query bit for bit;
 """
 import numpy as np
 import pytest
@@ -123,3 +125,189 @@ def test_large_merge_carries_the_refusal_marker_and_rejects_a_short_workspace():
     rc = lib.dewi_merge_rerank(nat.ptr(lists), 3, 2, c, c, k, 0.3, 0.0, nat.ptr(ids), nat.ptr(sc), nat.ptr(small), need - 8,
                                nat.stream_ptr())
     assert rc == nat.ERR_WORKSPACE and "workspace" in nat.last_error()
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_l2_batches_keep_near_duplicates_at_zero_distance(bf16):
+    """The default l2 batch path must give what the reference's -sum((E - q)^2) gives (backends.py:434-436) where it
+    matters most: queries that are (near-)duplicates of corpus rows with large norms.  On the matrix cores the score
+    2<e,q> - ||e||^2 - ||q||^2 would come back as +-1e-4 noise at ||e||^2 ~ 500 — so by default an l2 batch takes the
+    exact row kernels: search_batch(Q)[j] == search(Q[j]) bit for bit, the duplicate's score is the reference's to the
+    UNSCALED 1e-5 of north_star, and ranking among near neighbours follows the oracle."""
+    import torch
+    eng = _engine()
+    n, d, b, k = 70_000, 256, 12, 10
+    rng = np.random.default_rng(7)
+    norms = rng.uniform(0.5, 30.0, size=(n, 1)).astype(np.float32)
+    raw = orc.synth_corpus(n, d, seed=7) * norms                     # ||e|| from 0.5 to 30: ||e||^2 up to 900
+    rows = rng.choice(n, size=b, replace=False)
+    Q = raw[rows].copy()
+    Q[b // 2:] += rng.normal(0, 1e-3, size=(b - b // 2, d)).astype(np.float32)   # second half: near, not exact, duplicates
+    for j in range(b):                                                # a few more close rows around every query
+        near = rng.choice(n, size=3, replace=False)
+        raw[near] = Q[j] + rng.normal(0, 3e-3, size=(3, d)).astype(np.float32)
+    raw[rows[: b // 2]] = Q[: b // 2]
+    cols = orc.synth_payload_columns(n, seed=7)
+    c = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"], space="l2")
+    dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    if bf16:
+        c = c.to_bf16()
+        E = c.emb.float().cpu().numpy()
+        Qo = np.stack([orc.bf16_round(q) for q in Q])                # l2: queries are rounded, not normalised
+    else:
+        E, Qo = raw, Q
+    ids, sc = c.search(Q, k, 0.0, 0.0)                               # eta = 0: the score IS the similarity
+    one = [c.search(Q[j], k, 0.0, 0.0) for j in range(b)]
+    for j in range(b):
+        assert np.array_equal(ids[j], one[j][0][0]) and np.array_equal(sc[j], one[j][1][0]), j   # batch == single, bit for bit
+        ref_ids, ref_sc = orc.search_prepared(E, Qo[j], dewi32, ent32, k, 0.0, 0.0, "l2") if bf16 else \
+            orc.search(E, Qo[j], dewi32, ent32, k, 0.0, 0.0, "l2")
+        assert np.max(np.abs(sc[j].astype(np.float64) - ref_sc.astype(np.float64))[:4]) <= 1e-5, (j, sc[j][:4], ref_sc[:4])
+        if not bf16:                                                 # (bf16 rounding makes the planted rows exact ties)
+            assert ids[j][0] == ref_ids[0]
+        if j < b // 2 and not bf16:
+            assert ids[j][0] == rows[j] and sc[j][0] == 0.0           # an exact duplicate is at distance exactly 0
+        assert set(ids[j][:4].tolist()) == set(ref_ids[:4].tolist())  # the duplicate and its three planted neighbours
+
+
+def test_c5_device_resident_pipeline_equals_the_host_array_path(monkeypatch):
+    """Config C5 through the Python layer on CUDA tensors (the reference's caller: pipelines.py:180-223): I_hat written
+    into its row of the [7][N] signal table -> fit on the table's rows -> score -> fp32 dewi column -> column ingest of
+    the device embedding block -> build -> search.  While that runs, every device-to-host copy of more than 4096 elements
+    is an error; the answers must equal the host-array path's bit for bit (medians, MADs, scores, search results)."""
+    import torch
+    from dewi import signals
+    from dewi.index import DewiIndex
+    from dewi.scorer import DewiScorer
+    from dewi.types import SIGNAL_FIELDS
+    n, d, k = 1_000_000, 512, 10
+    g = torch.Generator(device="cuda")
+    g.manual_seed(42)
+    A = torch.randn((n, d), generator=g, device="cuda")
+    g.manual_seed(43)
+    B = torch.randn((n, d), generator=g, device="cuda")
+    B[::5] = A[::5] * 0.6 + B[::5] * 0.4
+    rs = np.random.RandomState(5)
+    sig = np.stack([rs.gamma(2, 0.5, n), rs.gamma(2, 0.5, n) * 1.5, rs.gamma(2, 0.3, n), rs.gamma(2, 0.3, n) * 1.5,
+                    np.zeros(n), rs.beta(1, 5, n), rs.beta(1, 10, n)]).astype(np.float32)
+    A_host, B_host = A.cpu().numpy(), B.cpu().numpy()           # taken BEFORE the device build normalises A in place
+    Q = np.random.RandomState(6).randn(4, d).astype(np.float32)
+    ids = [f"doc_{i:07d}" for i in range(n)]
+    S = torch.from_numpy(sig).cuda()                             # the signal table, [7][N] on the device
+
+    # ---- device-resident flow, with large device-to-host copies forbidden
+    real_cpu, real_tolist = torch.Tensor.cpu, torch.Tensor.tolist
+
+    def guarded(real):
+        def f(self, *a, **kw):
+            assert not (self.is_cuda and self.numel() > 4096), f"a {tuple(self.shape)} tensor was copied to the host"
+            return real(self, *a, **kw)
+        return f
+    monkeypatch.setattr(torch.Tensor, "cpu", guarded(real_cpu))
+    monkeypatch.setattr(torch.Tensor, "tolist", guarded(real_tolist))
+    signals.cross_modal_similarity(A, B, return_device=True, out=S[4])
+    cols = {name: S[j] for j, name in enumerate(SIGNAL_FIELDS)}
+    scorer = DewiScorer()
+    scorer.fit_stats_columns(cols)                               # in place on the table's rows: two kernels, no sync
+    f64_dev, dewi32_dev = scorer.score_batch_device(cols)        # statistics read by the kernel from the device
+    index = DewiIndex(dim=d, use_ann=False, rerank_eta=0.3)
+    index.add_batch_columns(ids, A, {"dewi": dewi32_dev, "ht_mean": S[0], "ht_q90": S[1], "hi_mean": S[2], "hi_q90": S[3],
+                                     "I_hat": S[4], "redundancy": S[5], "noise": S[6]})
+    index.build()
+    assert index._backend._corpus.emb.data_ptr() == A.data_ptr()            # the caller's block, used in place
+    res_dev = index.search_batch(Q, k=k)
+    monkeypatch.undo()
+
+    # ---- the same through host arrays
+    ihat_h = signals.cross_modal_similarity(A_host, B_host)
+    assert np.array_equal(ihat_h, S[4].cpu().numpy())
+    sig[4] = ihat_h
+    cols_h = {name: sig[j] for j, name in enumerate(SIGNAL_FIELDS)}
+    scorer_h = DewiScorer()
+    scorer_h.fit_stats_columns(cols_h)
+    assert scorer.stats.medians == scorer_h.stats.medians and scorer.stats.mads == scorer_h.stats.mads
+    dewi_h = scorer_h.score_batch(cols_h)
+    assert np.array_equal(dewi_h, f64_dev.cpu().numpy())
+    assert np.array_equal(dewi_h.astype(np.float32), dewi32_dev.cpu().numpy())
+    med, mad = orc.robust_fit(cols_h)                            # and the oracle: statistics bit-exact, scores to 2 ulp
+    assert scorer.stats.medians == med and scorer.stats.mads == mad
+    ref = orc.score({key: v.astype(np.float64) for key, v in cols_h.items()}, med, mad)
+    assert np.max(np.abs(dewi_h - ref) / ref) < 1e-15
+    index_h = DewiIndex(dim=d, use_ann=False, rerank_eta=0.3)
+    index_h.add_batch_columns(ids, A_host, {"dewi": dewi_h, "ht_mean": sig[0], "ht_q90": sig[1], "hi_mean": sig[2],
+                                            "hi_q90": sig[3], "I_hat": sig[4], "redundancy": sig[5], "noise": sig[6]})
+    res_h = index_h.search_batch(Q, k=k)
+    for rd, rh in zip(res_dev, res_h):
+        assert [(a[0], a[1]) for a in rd] == [(a[0], a[1]) for a in rh]
+        for a, b in zip(rd, rh):                                  # payloads made from the device columns: fp32 values
+            assert a[2].dewi == float(np.float32(b[2].dewi)) and a[2].ht_mean == b[2].ht_mean and a[2].I_hat == b[2].I_hat
+    again = index.search_batch(Q[:1], k=k)[0]
+    assert all(x[2] is y[2] for x, y in zip(again, res_dev[0]))  # the same Payload objects from then on
+
+
+def test_redundancy_top1_at_full_size():
+    """Config C5's redundancy leg at its full size (1 M x 512 text / image embeddings on the device): a self-join through
+    the batched bf16 matrix-core path.  The reduction is this build's own definition (the reference defines none:
+    SURVEY §8 F3, parity unpinned), so it is checked by properties and against a brute-force product on 64 sampled rows."""
+    import torch
+    from dewi import signals
+    n, d = 1_000_000, 512
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    T = torch.randn((n, d), generator=g, device="cuda")
+    I = torch.randn((n, d), generator=g, device="cuda")
+    I[1000:1064] = T[5000:5064] * 0.9 + I[1000:1064] * 0.1       # texts 5000.. have a close image of ANOTHER document
+    r = signals.redundancy_top1(T, I, return_device=True)
+    assert r.shape == (n,) and r.is_cuda and bool(torch.isfinite(r).all())
+    assert float(r.min()) > 0.1 and float(r.max()) <= 1.0 + 1e-3  # the best of a million random directions in 512 dims
+    assert float(r[5000:5064].min()) > 0.9
+    In = torch.nn.functional.normalize(I, dim=1).bfloat16().float()
+    sample = [0, 1, 17, 5000, 5063, 999_999] + np.random.RandomState(3).randint(0, n, 58).tolist()
+    for i in sample:
+        q = torch.nn.functional.normalize(T[i], dim=0).bfloat16().float()
+        sims = In @ q
+        sims[i] = -2.0                                            # any OTHER document
+        assert abs(float(sims.max()) - float(r[i])) < 2e-3, i
+
+
+def test_drain_repairs_a_refused_query_with_the_shards_id_offset():
+    """PipelinedSearcher.drain answers a query the matrix-core pass refused again on the exact kernels: the repaired
+    row must carry the shard's id offset like the rows dewi_knn_finish wrote."""
+    import torch
+    eng = _engine()
+    n, dim, k, b, off = 100_000, 256, 10, 40, 5_000_000
+    raw = orc.synth_corpus(n, dim, seed=3)
+    raw[50_000:90_000] = raw[7]
+    cols = orc.synth_payload_columns(n, seed=3)
+    c = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"], id_offset=off).to_bf16()
+    Q = orc.synth_queries(b, dim, seed=4)
+    Q[5] = raw[7]                                                 # overflows its survivor segments
+    want_ids, want_sc = c.search(Q, k, 0.3, 0.1)                  # blocking API: repaired, global ids
+    assert want_ids.min() >= off
+    q_dev = torch.from_numpy(Q).cuda()
+    raw_ids, _ = c.search_device(q_dev, k, 0.3, 0.1)
+    assert (raw_ids[5] == -1).all().item()
+    pipe = eng.PipelinedSearcher(c, k, 0.3, 0.1, n_queries=b)
+    ids = torch.empty((b, k), dtype=torch.int64, device="cuda")
+    sc = torch.empty((b, k), dtype=torch.float32, device="cuda")
+    pipe.submit(q_dev, ids, sc)
+    pipe.drain()
+    assert np.array_equal(ids.cpu().numpy(), want_ids) and np.array_equal(sc.cpu().numpy(), want_sc)
+
+
+def test_scorer_row_api_when_the_callers_list_grew_after_fit():
+    """fit_stats(rows) keeps the caller's list to serve score(sig) from one launch; dicts APPENDED to that list afterwards
+    are not in the fitted table and must simply be scored (the reference scores any dict), not raise."""
+    from dewi.scorer import DewiScorer
+    cols = orc.synth_payload_columns(300, seed=8)
+    rows = [{key: float(np.float32(cols[key][i])) for key in orc.SIGNAL_KEYS} for i in range(300)]
+    fitted = rows[:200]
+    s = DewiScorer()
+    s.fit_stats(fitted)
+    first = [s.score(r) for r in fitted[:5]]
+    fitted.extend(rows[200:])                                     # the list the scorer holds grows
+    later = [s.score(r) for r in fitted]                          # sequential scan walks past the fitted length
+    assert later[:5] == first
+    med, mad = s.stats.medians, s.stats.mads
+    ref = orc.score({key: np.array([r[key] for r in fitted], np.float64) for key in orc.SIGNAL_KEYS}, med, mad)
+    assert np.max(np.abs(np.array(later) - ref) / ref) < 1e-15
