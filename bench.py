@@ -149,16 +149,60 @@ def device_payload(torch, nat, cols, n, device):
     return dewi32, ent32
 
 
+def host_facts():
+    """What the host gives this job: logical CPUs visible / in the affinity mask, the cgroup CPU quota if any, CPU model."""
+    facts = {"os_cpu_count": os.cpu_count()}
+    try:
+        facts["sched_getaffinity"] = len(os.sched_getaffinity(0))
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                facts["cpu_model"] = line.split(":", 1)[1].strip()
+                break
+    except Exception:  # noqa: BLE001
+        pass
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            facts["cgroup_cpu_quota"] = open(f).read().strip()
+            break
+        except Exception:  # noqa: BLE001
+            continue
+    return facts
+
+
+def host_copy_first_touched_in_parallel(t_dev, workers=None, rows_per_chunk=4096):
+    """Device matrix -> host ndarray whose pages were FIRST TOUCHED by many threads (chunks of rows handed round-robin to
+    a thread pool), so that on a multi-socket / multi-NUMA host the matrix is spread over every node's memory instead of
+    sitting on the node of the one thread that copied it (which starves BLAS threads on the other nodes: the round-2
+    probe found 8 threads fastest on a 256-CPU box for that reason)."""
+    from concurrent.futures import ThreadPoolExecutor
+    src = t_dev.cpu().numpy()
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    workers = workers or max(1, min(64, avail))
+    dst = np.empty_like(src)                     # untouched pages
+    n = src.shape[0]
+    chunks = [(lo, min(n, lo + rows_per_chunk)) for lo in range(0, n, rows_per_chunk)]
+
+    def work(w):
+        for lo, hi in chunks[w::workers]:
+            dst[lo:hi] = src[lo:hi]              # numpy releases the GIL for the copy
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        list(pool.map(work, range(workers)))
+    return dst
+
+
 def best_blas_threads(fn):
     """The box may expose many more logical CPUs than this job's share; OpenBLAS then oversubscribes and
-    slows down.  Probe a few BLAS thread counts with fn() and return (fastest count, probe table, visible)."""
+    slows down.  Probe a ladder of BLAS thread counts with fn() and return (fastest count, probe table, visible)."""
     from threadpoolctl import threadpool_limits
     avail = os.cpu_count() or 1
     try:
         avail = len(os.sched_getaffinity(0))
     except Exception:  # noqa: BLE001
         pass
-    cands = sorted({t for t in (8, 16, 32, 64, 128, avail) if t <= avail})
+    cands = sorted({t for t in (8, 16, 24, 32, 48, 64, 96, 128, 192, avail) if t <= avail})
     probe = {}
     for t in cands:
         with threadpool_limits(limits=t, user_api="blas"):
@@ -499,7 +543,7 @@ def run_c2(args, torch, dist, eng, nat, rank, world, device):
     if rank == 0 and world == 1 and n_cpu > 0:
         orc, compare_query = oracle_imports()
         from threadpoolctl import threadpool_limits
-        E = corpus.emb.cpu().numpy()
+        E = host_copy_first_touched_in_parallel(corpus.emb)
         d32, e32 = dewi32.cpu().numpy(), ent32.cpu().numpy()
         nq = min(n_cpu, n_distinct)
         # GPU answers for exactly these queries (the timed run may have covered fewer of them)
@@ -526,11 +570,12 @@ def run_c2(args, torch, dist, eng, nat, rank, world, device):
         lat = np.array(lat)
         result["cpu_baseline"] = {"value": round(len(lat) / float(lat.sum()), 2), "unit": "queries/s", "cores": threads,
                                   "kind": "port", "p50_ms": round(float(np.percentile(lat, 50) * 1e3), 3),
-                                  "logical_cpus_visible": avail,
+                                  "logical_cpus_visible": avail, "host": host_facts(),
                                   "thread_probe_ms": {str(t): round(v * 1e3, 2) for t, v in probe.items()},
+                                  "matrix_first_touch": "parallel (chunks of 4096 rows round-robin over a thread pool)",
                                   "sample": f"{len(lat)} single queries of the same workload (full {total_rows}x{args.dim} "
                                             f"corpus) after 5 warm-up queries, NumPy/OpenBLAS oracle at its fastest BLAS "
-                                            f"thread count"}
+                                            f"thread count of the probe ladder"}
         # the reference's bare step sequence (E @ q + argpartition, backends.py:431-444) beside the full oracle
         with threadpool_limits(limits=threads, user_api="blas"):
             t1 = time.perf_counter()
@@ -663,7 +708,7 @@ def run_c3(args, torch, eng, nat, device):
     if args.cpu_queries > 0:
         orc, compare_query = oracle_imports()
         from threadpoolctl import threadpool_limits
-        Eb = cb.emb.float().cpu().numpy()
+        Eb = host_copy_first_touched_in_parallel(cb.emb.float())
         d32, e32 = dewi32.cpu().numpy(), ent32.cpu().numpy()
         nq = min(max(50, args.cpu_queries), B)
         Qp = eng.prepare_queries_bf16(Q[0]).float().cpu().numpy()      # the device's own prepared queries

@@ -100,6 +100,12 @@ constexpr int depth_lds_bytes() { return DepthGeo<BF16>::kRing * DepthGeo<BF16>:
 #ifndef DEWI_F32_SPLIT
 #define DEWI_F32_SPLIT 1
 #endif
+#ifndef DEWI_F32_DEFER_FILTER
+#define DEWI_F32_DEFER_FILTER 1   // filter (and survivor stores) of a tile one chunk later, right behind a barrier
+#endif
+#ifndef DEWI_F32_ABLATE_STORES
+#define DEWI_F32_ABLATE_STORES 0   // timing experiments only: 1 = survivors take their slots but are not stored (wrong results)
+#endif
 #ifndef DEWI_F32MFMA_DMA_AUX
 #define DEWI_F32MFMA_DMA_AUX 2   // non-temporal tile DMA: the corpus is read once
 #endif
@@ -342,12 +348,12 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
     };
     if (pend_doc0 != kNoDoc) {
       const uint32_t slot = take_slot();
-      if (slot < cap) seg[slot] = (static_cast<uint64_t>(pend_doc0) << 32) | __float_as_uint(pend_s0);
+      if (slot < cap && !DEWI_F32_ABLATE_STORES) seg[slot] = (static_cast<uint64_t>(pend_doc0) << 32) | __float_as_uint(pend_s0);
       pend_doc0 = kNoDoc;
     }
     if (pend_doc1 != kNoDoc) {
       const uint32_t slot = take_slot();
-      if (slot < cap) seg[slot] = (static_cast<uint64_t>(pend_doc1) << 32) | __float_as_uint(pend_s1);
+      if (slot < cap && !DEWI_F32_ABLATE_STORES) seg[slot] = (static_cast<uint64_t>(pend_doc1) << 32) | __float_as_uint(pend_s1);
       pend_doc1 = kNoDoc;
     }
   };
@@ -416,6 +422,12 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
     }
   };
 
+  // l2 keeps the filter at the end of the iteration: it reads the row norms out of the reduction buffer, which the
+  // other waves refill at the end of the tile's last chunk (two chunks per tile: no barrier in between)
+  // other waves refill at the end of the tile's last chunk (two chunks per tile: no barrier in between); with ONE chunk
+  // per tile (dim 256) there is no later chunk of the same tile to move it to (the wave's own two registers of the
+  // partial block, own0 / own1, are replaced at the end of the next iteration)
+  constexpr bool kDeferFilter = DEWI_F32_DEFER_FILTER && !L2 && CH >= 2;
   u32x4f cur[G::kReads], nxt[G::kReads];
   f32x16f acc;
   auto reads_done = [&](u32x4f (&f)[G::kReads]) {
@@ -446,6 +458,16 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       read_chunk(nxt, static_cast<int>((g + 1) & RM));
+      // The filter of the previous tile — and with it the survivor stores — runs HERE, right behind the barrier, one
+      // chunk after its partial sums were collected (kDeferFilter).  On gfx9 a store counts in vmcnt like the LDS-DMA
+      // pieces, and loads and stores complete out of order with respect to each other, so the counted wait at the top
+      // of a chunk can only be written for the pieces: a store still in flight there makes the wait ask for as many
+      // MORE pieces (of chunk g+2, which nobody needs yet).  Issued at the END of an iteration — where the filter used
+      // to run — a store met that wait a few hundred cycles later and cost the whole workgroup the ring's slack, however
+      // few records it carried (25-45 us per 32-query pass: DESIGN §4.1d); issued here it has a full chunk period.
+      if constexpr (kDeferFilter) {
+        if (ch == 1 && it > 0) stage2_finish(it - 1);
+      }
       const bool finish_prev = ch == 0 && it > 0;      // the previous tile's partials were stored before this barrier
       if (finish_prev) stage2_load();
       const __amdgpu_buffer_rsrc_t rs4 = tile_rsrc(it + (ch + G::kRing) / CH);
@@ -507,7 +529,7 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
       reads_done(nxt);
       if (finish_prev) {
         stage2_pin();
-        stage2_finish(it - 1);
+        if constexpr (!kDeferFilter) stage2_finish(it - 1);
       }
 #pragma unroll
       for (int m = 0; m < G::kReads; ++m) cur[m] = nxt[m];
