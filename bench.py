@@ -810,6 +810,7 @@ def run_c4(args, torch, eng, nat, device):
     algo_bytes = n * dim * 4 + B * dim * 4
     hbm = algo_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     ms_per_step = elapsed / args.steps * 1e3
+    c4_traffic, c4_note = recorded_traffic(f"{n}x{dim}x4xB{B}", "scan_rows_f32")
     result = {
         "metric": "queries/sec, 8M×768 fp32 corpus as 8 doc-id shards of 1M, k=10, η=0.3 (BASELINE.json configs[3]) "
                   "REPLAYED ON ONE GPU: every shard scanned in turn, records merged; no wire",
@@ -822,7 +823,8 @@ def run_c4(args, torch, eng, nat, device):
                    "parallelism": f"{S} shards emulated on a single GPU (multi-GPU: unmeasured here)",
                    "ideal_8gpu_ms_per_step": round(ms_per_step / S, 5)},
         "roofline": {"bound": "hbm", "kernel": "scan_rows_f32", "achieved": round(hbm, 1), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 4), "traffic": None,
+                     "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 4), "traffic": c4_traffic,
+                     "traffic_source": c4_note + " (the same kernel over one 1M-row shard: the C2 record)",
                      "algorithmic_bytes_per_launch": algo_bytes, "mean_kernel_ms": round(kern_ms, 5),
                      "launches_timed": launches},
         "sharded_parity": {"queries_checked": n_chk, "mismatches_vs_single_8M_search": bad},
@@ -959,6 +961,9 @@ def run_c5(args, torch, nat, device):
     fit_bytes = 2 * 7 * n * 4                       # one median pass + one MAD pass
     score_bytes = 7 * n * 4 + n * 4
     ms_per_step = elapsed / args.steps * 1e3
+    cos_traffic, cos_note = recorded_traffic(f"rowcos_{n}x{dim}", "row_cosine_512_kernel<2>")
+    fit_t = [recorded_traffic(f"fit_{ph}_7x{n}", f"fit_fast_kernel<{'true' if ph == 'mad' else 'false'}>")[0] for ph in ("med", "mad")]
+    fit_note = recorded_traffic(f"fit_med_7x{n}", "fit_fast_kernel<false>")[1]
     result = {
         "metric": "documents/sec through the on-GPU scorer part of BASELINE.json configs[4]: I_hat row-cosine (d=512) + "
                   "robust fit (7 signals) + DEWI score, 1M documents",
@@ -974,10 +979,13 @@ def run_c5(args, torch, nat, device):
                                 "ratio": round(api_ms / raw_ms, 4), "results_bit_equal": same and stats_same},
         "roofline": {"bound": "hbm", "kernel": "row_cosine_512_kernel", "achieved": round(cos_bytes / (cos_ms * 1e-3) / 1e9, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(cos_bytes / (cos_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                     "traffic": None, "algorithmic_bytes_per_launch": cos_bytes, "mean_kernel_ms": round(cos_ms, 5),
+                     "traffic": cos_traffic, "traffic_source": cos_note,
+                     "algorithmic_bytes_per_launch": cos_bytes, "mean_kernel_ms": round(cos_ms, 5),
                      "launches_timed": MIN_ROOFLINE_LAUNCHES,
                      "robust_fit": {"ms": round(fit_ms, 5), "algorithmic_bytes": fit_bytes,
-                                    "frac": round(fit_bytes / (fit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                                    "frac": round(fit_bytes / (fit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "traffic": (fit_t[0] + fit_t[1]) if None not in fit_t else None,
+                                    "traffic_source": "fit_fast_kernel<false> + <true>, " + fit_note},
                      "score": {"ms": round(score_ms, 5), "algorithmic_bytes": score_bytes,
                                "frac": round(score_bytes / (score_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
     }

@@ -37,6 +37,8 @@ c = eng.DeviceCorpus(emb, torch.rand(n, device=dev), torch.rand(n, device=dev), 
 if bf16:
     c = c.to_bf16()
     del emb
+if space == "l2":
+    eng.tuning(0, 0, -1, 2)      # l2 on the matrix cores is opt-in (default: exact row kernels)
 elem = 2 if bf16 else 4
 args = [a for a in args if a not in ("--graph", "--split")]
 sizes = [int(a) for a in args] or [8, 32, 64, 256]

@@ -9,7 +9,7 @@
 # 3. scripts/summarize_pmc.py -> pmc_summary.{txt,json} and hbm_traffic.json (bench.py's roofline.traffic)
 # The program itself (python3 bench.py) follows `--` directly: no env/bash hop under the profiler.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 COMMIT=${2:-unknown}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -53,6 +53,8 @@ pmc WRITE_SIZE_c3 WRITE_SIZE --config c3 --steps 10 --warmup 2
 pmc SQ_LDS_c3 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES" --config c3 --steps 10 --warmup 2
 pmc SQ_MFMA_c3 "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_COEXEC_CYCLES" --config c3 --steps 10 --warmup 2
 pmc SQ_WAIT_c3 "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" --config c3 --steps 10 --warmup 2
+pmc FETCH_SIZE_c5 FETCH_SIZE --config c5 --steps 10 --warmup 2
+pmc WRITE_SIZE_c5 WRITE_SIZE --config c5 --steps 10 --warmup 2
 probe_trace f32b32 32
 probe_trace bf16b32 --bf16 32
 probe_trace f32l2b32 --l2 32
@@ -61,5 +63,10 @@ probe_pmc FETCH_SIZE_f32l2b32 FETCH_SIZE --l2 32
 probe_pmc FETCH_SIZE_f32b32 FETCH_SIZE 32
 probe_pmc SQ_MFMA_f32b32 "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" 32
 probe_pmc SQ_LDS_f32b32 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" 32
-python3 scripts/summarize_pmc.py $OUT --commit $COMMIT --record "1000000x768x4xB1=scan_rows_f32" "1000000x768x2xB256=mfma_scan_bf16_s16<48, false>" > $OUT/pmc_summary.txt
+probe_pmc WRITE_SIZE_f32b32 WRITE_SIZE 32
+probe_pmc SQ_WAIT_f32b32 "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_WR" 32
+probe_pmc WRITE_SIZE_bf16b32 WRITE_SIZE --bf16 32
+python3 scripts/summarize_pmc.py $OUT --commit $COMMIT --record "1000000x768x4xB1=scan_rows_f32" "1000000x768x2xB256=mfma_scan_bf16_s16<48, false>" \
+  "1000000x768x4xB32=mfma_scan_f32<false, 3, false, false>" "1000000x768x2xB32=mfma_scan_f32<true, 3, false, false>" \
+  "rowcos_1000000x512=row_cosine_512_kernel<2>" "fit_med_7x1000000=fit_fast_kernel<false>" "fit_mad_7x1000000=fit_fast_kernel<true>" > $OUT/pmc_summary.txt
 cat $OUT/pmc_summary.txt
