@@ -459,12 +459,15 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
       asm volatile("" ::: "memory");
       read_chunk(nxt, static_cast<int>((g + 1) & RM));
       // The filter of the previous tile — and with it the survivor stores — runs HERE, right behind the barrier, one
-      // chunk after its partial sums were collected (kDeferFilter).  On gfx9 a store counts in vmcnt like the LDS-DMA
-      // pieces, and loads and stores complete out of order with respect to each other, so the counted wait at the top
-      // of a chunk can only be written for the pieces: a store still in flight there makes the wait ask for as many
-      // MORE pieces (of chunk g+2, which nobody needs yet).  Issued at the END of an iteration — where the filter used
-      // to run — a store met that wait a few hundred cycles later and cost the whole workgroup the ring's slack, however
-      // few records it carried (25-45 us per 32-query pass: DESIGN §4.1d); issued here it has a full chunk period.
+      // chunk after its partial sums were collected (kDeferFilter).  A store counts in vmcnt like the LDS-DMA pieces, in
+      // issue order, so one still in flight at the counted wait at the top of a chunk makes that wait ask for as many MORE
+      // pieces (of chunk g+2, which nobody needs yet).  Issued at the END of an iteration — where the filter used to run —
+      // a store met that wait a few hundred cycles later; issued here it has a full chunk period.  Measured A/B on one box
+      // (profiles/r03/README.md): 32-query pass 0.458-0.464 ms here against 0.466-0.467 with the filter at the end; with the
+      // stores stubbed 0.450.  (Adding the stores in flight to the wait's count instead — vmcnt(kWaitPieces + stores of the
+      // last two iterations), valid because the count is in issue order — made the pass SLOWER, 0.479 vs 0.464: the wait's
+      // slack is not what the remaining 8-14 us are; what is left is the flush itself — an LDS-counter round trip and a
+      // store in ONE wave while the other seven wait for it at the next barrier, 32 times per workgroup and pass.)
       if constexpr (kDeferFilter) {
         if (ch == 1 && it > 0) stage2_finish(it - 1);
       }
