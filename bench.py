@@ -169,6 +169,14 @@ def host_facts():
             break
         except Exception:  # noqa: BLE001
             continue
+    # cgroup v2 "cpu.max" = "<quota us> <period us>" (or "max ..."): the CPUs' worth of time this job may use, however
+    # many logical CPUs it can be scheduled on — threads beyond it only get throttled
+    try:
+        quota, period = facts.get("cgroup_cpu_quota", "").split()[:2]
+        if quota != "max":
+            facts["cpus_worth_of_quota"] = round(int(quota) / int(period), 2)
+    except Exception:  # noqa: BLE001
+        pass
     return facts
 
 
