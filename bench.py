@@ -254,8 +254,8 @@ def run_c2(args, torch, dist, eng, nat, rank, world, device):
     full = full_cols = None
     if args.scaling == "strong":
         total_rows = args.docs
-        lo = (total_rows * rank) // world
-        hi = (total_rows * (rank + 1)) // world
+        from dewi.sharded import shard_bounds
+        lo, hi = shard_bounds(total_rows, world)[rank]        # balanced, even boundaries (see its docstring)
         # every rank generates the same full stream and keeps its slice: identical to the 1-GPU corpus
         full, full_cols = make_corpus(torch, total_rows, args.dim, 42, device)
         emb_raw = full[lo:hi].clone() if world > 1 else full

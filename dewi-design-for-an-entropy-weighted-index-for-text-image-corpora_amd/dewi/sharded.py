@@ -28,8 +28,14 @@ RECORD_WORDS = 4  # sim, dewi, ent (fp32 bit patterns) + id, as int32 words
 
 
 def shard_bounds(n_total: int, world: int) -> List[Tuple[int, int]]:
-    """Contiguous, balanced row ranges: shard r = [n*r//world, n*(r+1)//world)."""
-    return [((n_total * r) // world, (n_total * (r + 1)) // world) for r in range(world)]
+    """Contiguous, balanced row ranges with EVEN boundaries: shard r = [cut(r), cut(r+1)), cut(r) = n*r//world
+    rounded to the nearest even row (the last shard ends at n; sizes differ by at most 3).  Why even: the one-query kernel of a bf16 corpus takes
+    1536-byte rows (dim 768) in PAIRS, and a row's fp32 sum is accumulated in a different lane order for the first
+    and the second row of a pair; a shard that starts on an odd row flips every row's place in its pair, and its
+    scores then agree with the whole-corpus search to summation noise (~1e-7) instead of bit for bit.  With even
+    boundaries "sharded == single device, bit for bit" holds for every element type and kernel."""
+    cuts = [((n_total * r) // world + 1) & ~1 for r in range(world)] + [n_total]
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
 class ShardedSearcher:

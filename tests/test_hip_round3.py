@@ -311,3 +311,100 @@ def test_scorer_row_api_when_the_callers_list_grew_after_fit():
     med, mad = s.stats.medians, s.stats.mads
     ref = orc.score({key: np.array([r[key] for r in fitted], np.float64) for key in orc.SIGNAL_KEYS}, med, mad)
     assert np.max(np.abs(np.array(later) - ref) / ref) < 1e-15
+
+
+def test_device_ingest_paths_equal_host_ingest(tmp_path):
+    """ExactIndex.add_batch_columns with CUDA tensors on its other paths — several device blocks, a host block in
+    between, rows appended to a built index, copy=True, space l2 (no normalisation), save / load and iteration over
+    the payload store afterwards — each equal to the same rows ingested as host arrays."""
+    import torch
+    from dewi.backends import ExactIndex
+    n, d, k = 3000, 64, 7
+    raw = orc.synth_corpus(n, d, seed=21)
+    cols = orc.synth_payload_columns(n, seed=21)
+    ids = [f"d{i}" for i in range(n)]
+    Q = orc.synth_queries(5, d, seed=22)
+    fields = ("dewi", "ht_mean", "hi_mean", "noise")
+    host_cols = {f: cols[f] for f in fields}
+
+    def dev_cols(lo, hi):
+        return {f: torch.from_numpy(cols[f][lo:hi]).cuda() for f in fields}          # float64 device columns
+
+    for space in ("cosine", "l2"):
+        ref = ExactIndex(dim=d, space=space)
+        ref.add_batch_columns(ids, raw, host_cols)
+        want = ref.search_batch(Q, k, 0.3, 0.2)
+        # (a) three blocks: device, host, device
+        a = ExactIndex(dim=d, space=space)
+        a.add_batch_columns(ids[:1000], torch.from_numpy(raw[:1000]).cuda(), dev_cols(0, 1000))
+        a.add_batch_columns(ids[1000:1800], raw[1000:1800], {f: cols[f][1000:1800] for f in fields})
+        a.add_batch_columns(ids[1800:], torch.from_numpy(raw[1800:]).cuda(), dev_cols(1800, n))
+        got = a.search_batch(Q, k, 0.3, 0.2)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), space
+        # (b) rows appended to a built index (stored rows are not normalised twice)
+        b = ExactIndex(dim=d, space=space)
+        b.add_batch_columns(ids[:2000], torch.from_numpy(raw[:2000]).cuda(), dev_cols(0, 2000))
+        b.build()
+        assert b.search_batch(Q, k, 0.3, 0.2)[0].max() < 2000
+        b.add_batch_columns(ids[2000:], torch.from_numpy(raw[2000:]).cuda(), dev_cols(2000, n))
+        got = b.search_batch(Q, k, 0.3, 0.2)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), space
+        # (c) copy=True leaves the caller's tensor alone; the default normalises it in place (cosine)
+        mine = torch.from_numpy(raw).cuda()
+        c = ExactIndex(dim=d, space=space)
+        c.add_batch_columns(ids, mine, dev_cols(0, n), copy=True)
+        c.build()
+        assert torch.equal(mine.cpu(), torch.from_numpy(raw))
+        got = c.search_batch(Q, k, 0.3, 0.2)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), space
+        # results carry Payload objects built from the device columns; whole-store views bring the block over
+        res = c.results_for(got[0][:1], got[1][:1])[0]
+        assert [r[0] for r in res] == [ids[i] for i in got[0][0]]
+        assert all(r[2].noise == cols["noise"][i] and r[2].dewi == cols["dewi"][i] for r, i in zip(res, got[0][0]))
+        assert len(c._payloads) == n and sum(1 for _ in c._payloads.values()) == n
+        # (d) save / load round trip of a device-ingested index, then refresh_payloads after an in-place edit
+        c.save(tmp_path / space)
+        back = ExactIndex.load(tmp_path / space)
+        got = back.search_batch(Q, k, 0.3, 0.2)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), space
+        top = int(want[0][0][0])
+        c._payloads[ids[top]].dewi = -5.0
+        c.refresh_payloads()
+        assert c.search_batch(Q[:1], k, 0.9, 0.0)[0][0][0] != top or k == 1     # a very low dewi at eta 0.9 drops the row
+
+
+def test_bf16_dim768_shards_are_bit_equal_on_even_boundaries():
+    """Found by scripts/fuzz_parity.py: the one-query kernel of a bf16 corpus scans 1536-byte rows (dim 768) in PAIRS and
+    sums the first and the second row of a pair in different lane orders, so a shard that starts on an ODD row scores its
+    rows with the other order: equal to the whole-corpus search to summation noise, not bit for bit.  shard_bounds cuts on
+    even rows, where candidates + merge == whole holds bit for bit; an odd cut is still the oracle's answer."""
+    import torch
+    from dewi.sharded import shard_bounds
+    eng = _engine()
+    n, d, k, eta, pref = 7778, 768, 40, 0.0, 0.0
+    raw = orc.synth_corpus(n, d, seed=91)
+    cols = orc.synth_payload_columns(n, seed=91)
+    Q = orc.synth_queries(1, d, seed=92)
+    whole = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"]).to_bf16()
+    qd = torch.from_numpy(Q).cuda()
+    w_ids, w_sc = whole.search_device(qd, k, eta, pref)
+    c = 2 * k
+
+    def sharded(cuts):
+        lists = [eng.DeviceCorpus(whole.emb[lo:hi], whole.dewi32[lo:hi], whole.ent32[lo:hi], "cosine", id_offset=lo)
+                 .candidates_device(qd, c) for lo, hi in zip(cuts[:-1], cuts[1:])]
+        return eng.merge_rerank_device(torch.stack(lists), c, k, eta, pref)
+
+    for world in (2, 3, 5, 8):
+        b = shard_bounds(n, world)
+        ids, sc = sharded([lo for lo, _ in b] + [n])
+        assert torch.equal(ids, w_ids) and torch.equal(sc, w_sc), world
+    ids, sc = sharded([0, 1637, 6445, 6861, n])                    # odd cuts: the fuzz case
+    E = whole.emb.float().cpu().numpy()
+    dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    from parity import device_prepared_queries
+    Qp = device_prepared_queries(Q)
+    _, msg = compare_query(E, Qp[0], dewi32, ent32, k, eta, pref, "cosine", ids[0].cpu().numpy(), sc[0].cpu().numpy(),
+                           gap=1e-6, score_tol=1e-5, prepared=True)
+    assert msg is None, msg
+    assert torch.allclose(torch.sort(sc, dim=1).values, torch.sort(w_sc, dim=1).values, rtol=0, atol=1e-6)

@@ -141,7 +141,8 @@ def test_shard_bounds_cover_everything():
         for w in (1, 2, 3, 8):
             b = shard_bounds(n, w)
             assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
-            assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1
+            assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 3 and all(hi >= lo for lo, hi in b)
+            assert all(lo % 2 == 0 for lo, _ in b)          # even boundaries: a row keeps its place in a bf16 row pair
 
 
 # ---- GPU: two ranks share cuda:0, real kernels, gloo staging ------------------------------------
