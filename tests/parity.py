@@ -76,9 +76,14 @@ def compare_query(E, q, dewi32, ent32, k, eta, pref, space, got_ids, got_scores,
     cut_gap = v_c - v_c1
     top = np.sort(adj64[order[:c]])[::-1][: min(k + 1, c)]
     rank_gap = np.inf if top.shape[0] < 2 else float(np.min(top[:-1] - top[1:]))
-    scale = max(1.0, float(np.max(np.abs(ref_sc))))
+    # Noise scales with the magnitude of what is compared: the similarity cut with |similarity at the cut| (l2 scores are
+    # -||e - q||^2, hundreds; at eta = 1 the ADJUSTED scores stay O(1) while the cut still happens among those hundreds —
+    # found by scripts/fuzz_parity.py), the ranking with the adjusted scores (which carry w_sim times the similarity).
+    sim_scale = max(1.0, float(abs(v_c))) if np.isfinite(v_c) else 1.0
+    scale = max(1.0, float(np.max(np.abs(ref_sc))), float(abs(np.float32(1 - eta))) * sim_scale)
+    g_cut = gap * sim_scale
     g = gap * scale
-    decisive = bool(min(cut_gap, rank_gap) > g)
+    decisive = bool(cut_gap > g_cut and rank_gap > g)
     if np.isnan(s64).any():
         # NaN rows (zero-norm embeddings) rank first as in NumPy: order among them is an artefact, so only
         # the exact comparison is meaningful and only when nothing else is near a tie
@@ -100,9 +105,9 @@ def compare_query(E, q, dewi32, ent32, k, eta, pref, space, got_ids, got_scores,
         return decisive, "duplicate rows in the result"
     nan_rows = np.isnan(s64)
     ok_rows = ~nan_rows[gi]
-    if np.any(s64[gi][ok_rows] < v_c - g) and not np.isnan(v_c):
-        bad = gi[ok_rows][s64[gi][ok_rows] < v_c - g]
-        return decisive, f"rows {bad.tolist()} are not among the top-{c} similarities (cut {v_c:.7f}, gap {g:.1e})"
+    if np.any(s64[gi][ok_rows] < v_c - g_cut) and not np.isnan(v_c):
+        bad = gi[ok_rows][s64[gi][ok_rows] < v_c - g_cut]
+        return decisive, f"rows {bad.tolist()} are not among the top-{c} similarities (cut {v_c:.7f}, gap {g_cut:.1e})"
     want_sc = _row_scores32(s32, gi, dewi32, ent32, eta, pref)
     with np.errstate(invalid="ignore"):
         err = np.abs(got_scores.astype(np.float64) - want_sc.astype(np.float64))
@@ -110,7 +115,7 @@ def compare_query(E, q, dewi32, ent32, k, eta, pref, space, got_ids, got_scores,
     if err.size and not float(np.max(err)) <= score_tol * scale:
         return decisive, f"near-tie query: score of a returned row off by {float(np.max(err)):.3e}"
     if not nan_rows.any():
-        sure = s64 > v_c1 + g if c < n else np.ones(n, dtype=bool)
+        sure = s64 > v_c1 + g_cut if c < n else np.ones(n, dtype=bool)
         sure[gi] = False
         worst = float(np.min(adj64[gi]))
         if np.any(adj64[sure] > worst + g):
@@ -169,6 +174,8 @@ def count_decisive(E, Q, dewi32, ent32, k, eta, pref, space, exact_gaps=True, ga
         cut_gap = s64[order[c - 1]] - (s64[order[c]] if c < n else -np.inf)
         top = np.sort(adj64[order[:c]])[::-1][: min(k + 1, c)]
         rank_gap = np.inf if top.shape[0] < 2 else float(np.min(top[:-1] - top[1:]))
-        scale = max(1.0, float(np.max(np.abs(ref_sc))) if ref_sc.size else 1.0)
-        n_dec += 1 if min(cut_gap, rank_gap) > gap * scale and not np.isnan(s64).any() else 0
+        v_c = s64[order[c - 1]]
+        sim_scale = max(1.0, float(abs(v_c))) if np.isfinite(v_c) else 1.0
+        scale = max(1.0, float(np.max(np.abs(ref_sc))) if ref_sc.size else 1.0, float(abs(np.float32(1 - eta))) * sim_scale)
+        n_dec += 1 if (cut_gap > gap * sim_scale and rank_gap > gap * scale) and not np.isnan(s64).any() else 0
     return n_dec

@@ -174,7 +174,8 @@ def test_mfma_l2_batched_vs_oracle(bf16, dim, n, b, k):
     ids_d, sc_d = c.search_device(torch.from_numpy(Q).cuda(), k, 0.3, 0.1)
     ids, sc = ids_d.cpu().numpy(), sc_d.cpu().numpy()
     assert ids.min() >= 0 and not np.isnan(sc).any()
-    check_batch(E, Qo, dewi32, ent32, k, 0.3, 0.1, "l2", ids, sc, min_decisive_frac=0.8 if k <= 10 else 0.25, **kw)
+    # (floor 0.2 at k = 100: the harness scales the cut gap by |similarity at the cut| — hundreds in l2 — since round 3)
+    check_batch(E, Qo, dewi32, ent32, k, 0.3, 0.1, "l2", ids, sc, min_decisive_frac=0.8 if k <= 10 else 0.2, **kw)
     # the same rows as the exact row-per-wave l2 kernels (matrix-core paths switched off), up to near-tie swaps
     eng.tuning(0, 0, -1, 0)
     try:
