@@ -221,8 +221,11 @@ BatchPlan plan_batch(int elem_type, int64_t n_rows, int dim, int n_queries, int 
   // space l2 on the matrix cores is scored 2<e,q> - ||e||^2 - ||q||^2: absolute error ~ulp(||e||^2 + ||q||^2), where the
   // reference's -sum((e - q)^2) (backends.py:434-436) has a small RELATIVE error of the distance — a near-duplicate of the
   // query would come back as +-1e-4 noise instead of ~0 and search_batch(Q)[j] would differ from search(Q[j]).  Parity
-  // first: l2 batches take the exact row kernels unless the calling thread opted in (dewi_tuning_set batched_mfma = 2).
-  const bool mfma = g_tuning.mfma != 0 && P.c_local == n_candidates && (space == DEWI_SPACE_COSINE || g_tuning.mfma == 2);
+  // first: over an fp32 corpus the pass runs in EXACT-REFINE mode (error-widened cut, candidates re-scored with the row
+  // kernels' arithmetic: batch_select); over a bf16 corpus l2 batches take the exact row kernels unless the calling thread
+  // opted in to the approximate form (dewi_tuning_set batched_mfma = 2).
+  const bool mfma = g_tuning.mfma != 0 && P.c_local == n_candidates &&
+                    (space == DEWI_SPACE_COSINE || elem_type == 0 || g_tuning.mfma == 2);
   const bool depth_ok = mfma && dewi::mfma_f32_path_supported(elem_type, n_rows, dim, n_queries, n_candidates, space);
   const bool big_ok = mfma && elem_type == 1 && dewi::mfma_path_supported(n_rows, dim, n_queries, n_candidates, space);
   if (depth_ok && (elem_type == 0 || n_queries <= 32 || !big_ok)) {
@@ -261,9 +264,12 @@ int batch_scan(const BatchPlan& P, const void* d_E, int elem_type, int64_t n_row
 
 // k > 0: ids / scores of the re-ranked top k.  k == 0: n_candidates records per query into d_out_cand (an overflowed
 // query of a matrix-core path carries id -2 there, -1 in the id output).
+// d_E / elem_type / dim / space: the corpus the scan ran over — the exact-refine mode of l2 over an fp32 corpus re-scores
+// its candidates from the rows themselves.
 int batch_select(const BatchPlan& P, void* d_ws, size_t ws_bytes, int n_queries, int n_candidates, int k,
                  const dewi::RerankParams& rp, const float* d_dewi32, const float* d_ent32, int64_t id_offset,
-                 int64_t* d_out_ids, float* d_out_scores, dewi_candidate* d_out_cand, hipStream_t stream) {
+                 int64_t* d_out_ids, float* d_out_scores, dewi_candidate* d_out_cand, hipStream_t stream,
+                 const void* d_E, int elem_type, int dim, int space) {
   if (!d_ws || ws_bytes < P.total) return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, P.total);
   char* ws = static_cast<char*>(d_ws);
   hipError_t e = hipSuccess;
@@ -295,15 +301,23 @@ int batch_select(const BatchPlan& P, void* d_ws, size_t ws_bytes, int n_queries,
   const size_t cand_off = big ? P.big.cand_off : P.depth.cand_off, cnt_off = big ? P.big.cnt_off : P.depth.cnt_off;
   // counts: query-major for the 256-query pass (coalesced in the select kernel), segment-major for the depth-split pass
   const dewi::SegmentLayout seg{n_seg, seg_cap, 1, static_cast<int64_t>(per) * seg_cap, big ? 1 : per, 8192, big ? n_seg : 1};
+  const bool refine = !big && space == DEWI_SPACE_L2 && elem_type == 0;
+  if (refine && !d_E) return fail(DEWI_ERR_INVALID_ARG, "l2 over an fp32 corpus: the finish step needs the corpus pointer");
   for (int g = 0; g < groups && e == hipSuccess; ++g) {
     const int q0 = g * per;
     const int nq = n_queries - q0 < per ? n_queries - q0 : per;
     const uint64_t* keys = reinterpret_cast<const uint64_t*>(ws + cand_off) + static_cast<int64_t>(g) * n_seg * per * seg_cap;
     const uint32_t* counts = reinterpret_cast<const uint32_t*>(ws + cnt_off) + static_cast<int64_t>(g) * n_seg * per;
+    dewi::RefineParams rf{nullptr, nullptr, nullptr, 0, 0.f};
+    if (refine)   // the raw queries and their squared norms as the scan left them in the workspace
+      rf = dewi::RefineParams{static_cast<const float*>(d_E),
+                              reinterpret_cast<const float*>(ws + P.depth.qn_off) + static_cast<int64_t>(q0) * dim,
+                              reinterpret_cast<const float*>(ws + P.depth.qn2_off) + q0, dim, dewi::depth_l2_margin(dim)};
     e = dewi::launch_select_rerank(keys, 0, 0, nq, n_candidates, k, rp, d_dewi32, d_ent32, id_offset,
                                    d_out_ids ? d_out_ids + static_cast<int64_t>(q0) * k : nullptr,
                                    d_out_scores ? d_out_scores + static_cast<int64_t>(q0) * k : nullptr,
-                                   d_out_cand ? d_out_cand + static_cast<int64_t>(q0) * n_candidates : nullptr, counts, seg, stream);
+                                   d_out_cand ? d_out_cand + static_cast<int64_t>(q0) * n_candidates : nullptr, counts, seg, stream,
+                                   rf);
   }
   return e == hipSuccess ? DEWI_OK : hip_fail(e, "select launch");
 }
@@ -336,7 +350,8 @@ int knn_rerank_impl(const void* d_E, int elem_type, int64_t n_rows, int dim, con
   rc = batch_scan(P, d_E, elem_type, n_rows, dim, d_Q, n_queries, c, space, d_ws, ws_bytes, dev.cus, stream);
   if (rc) return rc;
   const dewi::RerankParams rp = make_rerank(eta, pref, transform, space);
-  return batch_select(P, d_ws, ws_bytes, n_queries, c, k, rp, d_dewi32, d_ent32, 0, d_out_ids, d_out_scores, nullptr, stream);
+  return batch_select(P, d_ws, ws_bytes, n_queries, c, k, rp, d_dewi32, d_ent32, 0, d_out_ids, d_out_scores, nullptr, stream, d_E,
+                      elem_type, dim, space);
 }
 
 }  // namespace
@@ -451,7 +466,7 @@ int dewi_knn_scan(const void* d_E, int elem_type, int64_t n_rows, int dim, const
                     static_cast<hipStream_t>(stream_));
 }
 
-int dewi_knn_finish(void* d_workspace, size_t workspace_bytes, int elem_type, int64_t n_rows, int dim,
+int dewi_knn_finish(void* d_workspace, size_t workspace_bytes, const void* d_E, int elem_type, int64_t n_rows, int dim,
                     int n_queries, int n_candidates, int space, int k, double eta, double entropy_pref,
                     const float* d_dewi32, const float* d_ent32, int64_t id_offset, int64_t* d_out_ids,
                     float* d_out_scores, dewi_candidate* d_out_cand, void* stream_) {
@@ -476,7 +491,7 @@ int dewi_knn_finish(void* d_workspace, size_t workspace_bytes, int elem_type, in
   return batch_select(P, d_workspace, workspace_bytes, n_queries, n_candidates, records ? 0 : k,
                       make_rerank(records ? 0.0 : eta, records ? 0.0 : entropy_pref, DEWI_SIM_RAW, space), d_dewi32, d_ent32,
                       id_offset, records ? nullptr : d_out_ids, records ? nullptr : d_out_scores, d_out_cand,
-                      static_cast<hipStream_t>(stream_));
+                      static_cast<hipStream_t>(stream_), d_E, elem_type, dim, space);
 }
 
 int dewi_knn_rerank_bf16(const uint16_t* d_E, int64_t n_rows, int dim, const float* d_Q, int n_queries,
@@ -508,7 +523,7 @@ int dewi_knn_candidates(const void* d_E, int elem_type, int64_t n_rows, int dim,
   rc = batch_scan(P, d_E, elem_type, n_rows, dim, d_Q, n_queries, n_candidates, space, d_workspace, workspace_bytes, dev.cus, stream);
   if (rc) return rc;
   return batch_select(P, d_workspace, workspace_bytes, n_queries, n_candidates, 0, make_rerank(0.0, 0.0), d_dewi32, d_ent32,
-                      id_offset, nullptr, nullptr, d_out, stream);
+                      id_offset, nullptr, nullptr, d_out, stream, d_E, elem_type, dim, space);
 }
 
 size_t dewi_merge_workspace_bytes(int n_lists, int n_queries, int list_len, int n_candidates) {

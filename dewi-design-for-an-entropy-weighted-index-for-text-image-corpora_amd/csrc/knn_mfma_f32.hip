@@ -27,10 +27,15 @@
 // buffer and summed in a fixed order), so the corpus is still read once and nothing is stored per row.  The three
 // terms round at the magnitude of ||e||^2 + ||q||^2: an ABSOLUTE error of about an ulp of that magnitude, where the
 // reference's fp32 sum of squared differences has a relative error of the distance itself.  For rows far from the query
-// the two agree to fp32 noise; a near-duplicate of the query scores +-1e-4 here (||e||^2 ~ 500) and ~0 there.  The l2
-// form is therefore OPT-IN (dewi_tuning_set batched_mfma = 2): by default l2 batches take the exact row-per-wave
-// kernels (abi.cpp plan_batch).  tests/test_hip_mfma_f32.py opts in and compares with the oracle at gaps and tolerances
-// scaled by that magnitude; tests/test_hip_round3.py pins the default path on near-duplicate queries.  fp32
+// the two agree to fp32 noise; a near-duplicate of the query scores +-1e-4 here (||e||^2 ~ 500) and ~0 there.  So:
+//   * fp32 corpus: EXACT-REFINE mode (default).  |score - exact| <= l2_margin (||e||^2 + ||q||^2), l2_margin = 2 dim 2^-23
+//     (dim fp32 accumulations of products bounded by (e_i^2 + q_i^2) / 2, twice, the norm's own sum, three roundings).  The
+//     sample pass records score - margin, the filter passes score + margin >= threshold, and the select kernel
+//     (select_rerank.hip, refine_top_candidates) widens the cut by the bound and re-scores the candidates with the row
+//     kernels' arithmetic: the batch equals the one-query searches bit for bit (tests/test_hip_round3.py).
+//   * bf16 corpus: the form above unrefined is an OPT-IN (dewi_tuning_set batched_mfma = 2); by default l2 batches over a
+//     bf16 corpus take the exact row-per-wave kernels (abi.cpp plan_batch).  tests/test_hip_mfma_f32.py opts in and
+//     compares with the oracle at gaps and tolerances scaled by that magnitude.  fp32
 // corpora: dims up to 768 (beyond, query pieces + norm traffic do not fit the registers: such batches keep the
 // row-per-wave l2 kernels); bf16 corpora: every supported dim.  1 M x 768: fp32 32 queries 0.49 ms per pass
 // (cosine 0.47), bf16 0.225 ms — l2 batches used to cost a row-kernel pass per 4 (fp32) queries.
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
                                                                 int64_t tile_stride, const float* __restrict__ thr,
                                                                 uint64_t* __restrict__ out, int64_t out_stride,
                                                                 uint32_t* __restrict__ cnt, int n_active,
-                                                                const float* __restrict__ qn2) {
+                                                                const float* __restrict__ qn2, float l2_margin) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using G = DepthGeo<BF16>;
   constexpr int DIM = CH * kF32ChunkCols;
@@ -359,6 +364,7 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
   };
   auto stage2_finish = [&](int64_t it) {             // fixed summation order 0..7 whichever wave sums; then the filter
     float s0 = 0.f, s1 = 0.f;
+    float m0 = 0.f, m1 = 0.f;                        // l2: bound of |score - (-||e - q||^2)|, see l2_margin
 #pragma unroll
     for (int v = 0; v < kF32Waves; ++v) {
       const float p0 = v == w ? own0 : part[v][0], p1 = v == w ? own1 : part[v][1];
@@ -395,21 +401,28 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
       }
       s0 = (2.f * s0 - n0) - qn2_l;
       s1 = (2.f * s1 - n1) - qn2_l;
+      // EXACT-REFINE mode (fp32 corpus: l2_margin = 2 dim 2^-23): the three terms above carry an absolute error of at most
+      // l2_margin * (||e||^2 + ||q||^2) — dim fp32 accumulations of products bounded by (e_i^2 + q_i^2) / 2, twice, plus the
+      // norm's own sum and three roundings.  The sample pass records score - margin (the c-th largest of those is a lower
+      // bound of the c-th best EXACT score), the filter passes score + margin >= threshold (no row of the exact top c is
+      // lost), and the select kernel re-scores the candidates exactly (select_rerank.hip, refine_top_candidates).
+      m0 = l2_margin * (n0 + qn2_l);
+      m1 = l2_margin * (n1 + qn2_l);
     }
     const int64_t row0 = (first + it * step) * tile_stride * kF32TileRows;
     const int64_t doc = row0 + 2 * (w & 1) + 8 * (w >> 1) + 4 * h;     // register 2w; register 2w+1 is the next row
     if (doc >= n_rows) s0 = -__builtin_inff();                         // padding rows of the last tile never pass
     if (doc + 1 >= n_rows) s1 = -__builtin_inff();
     if constexpr (SAMPLE) {
-      mx0 = __builtin_fmaxf(mx0, s0);
-      mx1 = __builtin_fmaxf(mx1, s1);
+      mx0 = __builtin_fmaxf(mx0, s0 - m0);
+      mx1 = __builtin_fmaxf(mx1, s1 - m1);
     } else {
       // A survivor waits in its lane (one place per accumulator register) until a second one arrives for the same
       // place somewhere in the wave; then the whole wave's waiting records go out together.  A vector store issued
       // into the full DMA queue costs the workgroup ~0.1 us at its next barrier whether it carries one record or
       // sixty-four (a batch of 32 ran 40 us behind a batch of 8 on per-survivor stores; taking the LDS slots
       // alone cost nothing), and a wave collects ~14 survivors before two meet.
-      const bool pass0 = !(s0 < thr_l), pass1 = !(s1 < thr_l);         // NaN passes (NumPy ranks NaN first)
+      const bool pass0 = !(s0 + m0 < thr_l), pass1 = !(s1 + m1 < thr_l);   // NaN passes (NumPy ranks NaN first)
       if (__builtin_amdgcn_ballot_w64((pass0 && pend_doc0 != kNoDoc) || (pass1 && pend_doc1 != kNoDoc)) != 0ull) flush_pending();
       if (pass0) {
         pend_doc0 = static_cast<uint32_t>(doc);
@@ -573,6 +586,8 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+float depth_l2_margin(int dim) { return 2.f * static_cast<float>(dim) * 1.1920929e-7f; }   // 2 dim 2^-23
+
 bool mfma_f32_path_supported(int elem_type, int64_t n_rows, int dim, int n_queries, int n_candidates, int space) {
   const int ch = dim / kF32ChunkCols;
   const int min_q = elem_type ? kMfmaMinQueries : kMfmaF32MinQueries;
@@ -616,6 +631,9 @@ MfmaF32Layout plan_mfma_f32(int elem_type, int64_t n_rows, int dim, int n_querie
 template <bool BF16, int CH, bool L2>
 static hipError_t run_mfma_f32_dim(const MfmaF32Layout& m, const void* E, int64_t n_rows, int n_queries, int n_candidates,
                                    char* ws, hipStream_t stream) {
+  // l2 over an fp32 corpus runs in exact-refine mode (see stage2_finish and select_rerank.hip): error bound per unit of
+  // ||e||^2 + ||q||^2.  bf16 corpora (opt-in, approximate) and cosine: no margin.
+  const float l2_margin = (L2 && !BF16) ? depth_l2_margin(CH * kF32ChunkCols) : 0.f;
   constexpr int DIM = CH * kF32ChunkCols;
   constexpr int kLds = depth_lds_bytes<BF16>();
   static PerDeviceOnce attr_once;   // one per instantiation
@@ -643,7 +661,7 @@ static hipError_t run_mfma_f32_dim(const MfmaF32Layout& m, const void* E, int64_
     const float* q2g = qn2 + g * kF32Queries;
     hipLaunchKernelGGL((mfma_scan_f32<BF16, CH, true, L2>), dim3(m.sample_blocks), dim3(kF32Threads), kLds, stream, E, n_rows, qg,
                        m.n_sample_tiles, m.tile_stride, static_cast<const float*>(nullptr), reinterpret_cast<uint64_t*>(dense),
-                       m.sample_stride, static_cast<uint32_t*>(nullptr), n_active, q2g);
+                       m.sample_stride, static_cast<uint32_t*>(nullptr), n_active, q2g, l2_margin);
     // 2. per-query threshold: the c-th largest group maximum (real queries only)
     const hipError_t et = launch_sample_threshold(dense, m.sample_stride, m.sample_stride, n_candidates, tg, n_active, stream);
     if (et != hipSuccess) return et;
@@ -651,7 +669,7 @@ static hipError_t run_mfma_f32_dim(const MfmaF32Layout& m, const void* E, int64_
     timing_begin(stream);
     hipLaunchKernelGGL((mfma_scan_f32<BF16, CH, false, L2>), dim3(m.n_blocks), dim3(kF32Threads), kLds, stream, E, n_rows, qg,
                        m.n_tiles, static_cast<int64_t>(1), static_cast<const float*>(tg), og, static_cast<int64_t>(m.seg_cap), cg,
-                       n_active, q2g);
+                       n_active, q2g, l2_margin);
     timing_end(stream);
   }
   return hipGetLastError();

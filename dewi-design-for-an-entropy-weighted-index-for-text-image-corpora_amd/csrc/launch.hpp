@@ -137,6 +137,8 @@ struct MfmaF32Layout {
 // depth-split kernel on 32x32x16 bf16 MFMAs — batches of up to 32 queries at the tile-delivery rate, and the
 // dimensions the 256-query kernel of knn_mfma_bf16.hip cannot hold in registers: 1024, 1536)
 bool mfma_f32_path_supported(int elem_type, int64_t n_rows, int dim, int n_queries, int n_candidates, int space);
+// l2 over an fp32 corpus: |matrix-core score - (-||e - q||^2)| <= depth_l2_margin(dim) * (||e||^2 + ||q||^2)
+float depth_l2_margin(int dim);
 MfmaF32Layout plan_mfma_f32(int elem_type, int64_t n_rows, int dim, int n_queries, int n_candidates, int compute_units);
 hipError_t launch_mfma_f32(const MfmaF32Layout& m, int elem_type, const void* d_E, int64_t n_rows, int dim, const float* d_Q,
                            int n_queries, int n_candidates, int space, char* ws, hipStream_t stream);
@@ -171,11 +173,20 @@ struct SegmentLayout {
                                // depth-split pass) or n_seg with count_stride = 1 (query-major: a query's counts are
                                // contiguous and the select kernel reads them coalesced — the 256-query pass)
 };
+// Exact refinement of approximate survivor scores (l2 on the matrix cores, fp32 corpus): E != NULL switches it on.  The
+// select kernel widens the candidate cut by the error bound and re-scores the candidates with the row kernels' arithmetic.
+struct RefineParams {
+  const float* E;        // corpus rows [n_rows][dim] fp32 (NULL: off)
+  const float* Q;        // this launch's queries [n_queries][dim] fp32, as the scan used them (l2: raw)
+  const float* qn2;      // ||q||^2 per query
+  int dim;
+  float margin;          // depth_l2_margin(dim)
+};
 hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, int sorted_lists, int n_queries,
                                 int n_candidates, int k, const RerankParams& rp, const float* d_dewi32, const float* d_ent32,
                                 int64_t id_offset, int64_t* d_out_ids, float* d_out_scores,
                                 dewi_candidate* d_out_cand, const uint32_t* d_counts, const SegmentLayout& seg,
-                                hipStream_t stream);
+                                hipStream_t stream, const RefineParams& refine = RefineParams{nullptr, nullptr, nullptr, 0, 0.f});
 // c > kMaxSortCandidates: dense keys [n_queries][keys_per_query] in, scratch g1/g2 [n_queries][p2].
 // d_out_cand != NULL: n_out records per query (the shard's candidates) instead of final results.
 hipError_t launch_select_rerank_large(const uint64_t* d_keys, int64_t keys_per_query, int n_queries, int n_candidates,

@@ -167,6 +167,105 @@ __device__ int top_candidates_lds(const uint64_t* keys, int n, int n_candidates,
   return n_sel;
 }
 
+// EXACT REFINEMENT of approximate survivor scores (space l2 on the matrix cores over an fp32 corpus, RefineParams).
+// `keys` (dense LDS array, n unique keys) carry the matrix-core scores a = 2<e,q> - ||e||^2 - ||q||^2, each within
+//     M(a) = margin * (3 ||q||^2 + 2 d) * 1.01,   d = max(0, -a)
+// of the row's exact score: the kernel's bound is margin * (||e||^2 + ||q||^2), and ||e|| <= ||q|| + sqrt(d_exact) gives
+// ||e||^2 + ||q||^2 <= 3 ||q||^2 + 2 d_exact (the 1 % covers d_exact vs d).  Steps:
+//   1. a_c = the c-th largest approximate score (radix select as before); L = a_c - M(a_c) is a lower bound of the c-th
+//      best EXACT score (c rows have exact >= a - M(a) >= L, M growing with d);
+//   2. every key with a + M(a) >= L is a candidate (c' >= c of them; usually c plus a handful) — no row of the exact
+//      top c can be missing;
+//   3. one wave per candidate re-scores it with THE ROW KERNEL'S ARITHMETIC (scan_rows_f32<U, ..., l2>: lane l takes the
+//      16-byte units l + 64 u, u ascending, d = e - q, fmaf(d, d, acc); wave_sum_f32; negate), so the score — and with it
+//      the ranking — is bit for bit what the one-query search computes for that row (dim = 256 U);
+//   4. the exact keys are sorted, the best c stay in sh.sel.
+// Returns the number of valid keys in sh.sel, or -2 when more candidates qualify than sh.sel2 holds (adversarial: the
+// query is refused and the caller re-runs it on the row kernels).  `tmp`: at least kMaxSortCandidates keys of scratch
+// that is not `keys`... it IS `keys`: the dense array is dead once the candidates are compacted.
+__device__ __forceinline__ int refine_top_candidates(uint64_t* keys, int n, int n_candidates, SelectShared& sh,
+                                                     WideRadixShared& ws, const RefineParams& rf, int q) {
+  const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
+  const int lane = tid & 63, wave = tid >> 6, n_waves = nt >> 6;
+  const uint64_t thr = block_kth_largest_lds(keys, n, static_cast<uint32_t>(n_candidates), ws);
+  const float q2 = rf.qn2[q];
+  auto bound = [&](float a) {                      // M(a); NaN scores (NaN rows rank first) get an infinite bound
+    const float d = a < 0.f ? -a : 0.f;
+    return a == a ? rf.margin * (3.f * q2 + 2.f * d) * 1.01f : __builtin_inff();
+  };
+  float low = -__builtin_inff();                   // fewer than c keys: every key is a candidate
+  if (thr != 1ull) {
+    const float a_c = key_score(thr);
+    low = a_c - bound(a_c);
+    if (!(low == low)) low = -__builtin_inff();
+  }
+  if (tid == 0) sh.count = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += nt) {             // compaction: one LDS atomic per wave and round
+    const int i = i0 + tid;
+    const uint64_t key = i < n ? keys[i] : kKeyEmpty;
+    const float a = key_score(key);
+    const bool pass = key != kKeyEmpty && !(a + bound(a) < low);
+    const unsigned long long m = __ballot(pass);
+    if (m != 0ull) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&sh.count, static_cast<uint32_t>(__popcll(m)));
+      base = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(base)));
+      const uint32_t pos = base + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
+      if (pass && pos < static_cast<uint32_t>(kMaxSortCandidates)) sh.sel2[pos] = key;
+    }
+  }
+  __syncthreads();
+  const int n_cand = static_cast<int>(sh.count);
+  if (n_cand > kMaxSortCandidates) return -2;
+  // exact scores, one wave per candidate, kBatch candidates per wave and round with all their loads in flight together
+  // (the candidates of a query are a few dozen to a few hundred 3 KiB rows: latency, not bandwidth)
+  constexpr int kMaxUnits = 3, kBatch = 4;         // l2 over an fp32 corpus on the matrix cores: dim 256 / 512 / 768
+  const int units = rf.dim >> 8;                   // U = dim / 256 sixteen-byte units per lane
+  typedef float f32x4r __attribute__((ext_vector_type(4)));
+  const f32x4r* qp = reinterpret_cast<const f32x4r*>(rf.Q + static_cast<int64_t>(q) * rf.dim) + lane;
+  f32x4r qv[kMaxUnits];
+#pragma unroll
+  for (int u = 0; u < kMaxUnits; ++u) qv[u] = u < units ? qp[u * 64] : f32x4r{0.f, 0.f, 0.f, 0.f};
+  for (int t0 = wave * kBatch; t0 < n_cand; t0 += n_waves * kBatch) {
+    f32x4r e[kBatch][kMaxUnits];
+    uint32_t rows[kBatch];
+#pragma unroll
+    for (int bb = 0; bb < kBatch; ++bb) {
+      const int t = t0 + bb < n_cand ? t0 + bb : t0;
+      rows[bb] = key_row(sh.sel2[t]);
+      const f32x4r* ev = reinterpret_cast<const f32x4r*>(rf.E + static_cast<int64_t>(rows[bb]) * rf.dim) + lane;
+#pragma unroll
+      for (int u = 0; u < kMaxUnits; ++u) e[bb][u] = u < units ? ev[u * 64] : f32x4r{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int bb = 0; bb < kBatch; ++bb) {
+      float acc = 0.f;
+#pragma unroll
+      for (int u = 0; u < kMaxUnits; ++u) {         // u ascending, x y z w: scan_rows_f32's accum4<l2>.  Unrolled with a
+        if (u < units) {                            // uniform guard: a run-time index would put e[][] into scratch memory
+          float d;
+          d = e[bb][u].x - qv[u].x; acc = __builtin_fmaf(d, d, acc);
+          d = e[bb][u].y - qv[u].y; acc = __builtin_fmaf(d, d, acc);
+          d = e[bb][u].z - qv[u].z; acc = __builtin_fmaf(d, d, acc);
+          d = e[bb][u].w - qv[u].w; acc = __builtin_fmaf(d, d, acc);
+        }
+      }
+      const float sc = -wave_sum_f32(acc);
+      if (lane == 0 && t0 + bb < n_cand) keys[t0 + bb] = make_key(sc, rows[bb]);   // the dense array is scratch now
+    }
+  }
+  __syncthreads();
+  if (n_cand <= 1024) {          // one ranking pass (n^2 / threads compares, one barrier) beats the 45-66 barriers of the bitonic network here
+    rank_sort_desc(keys, sh.sel, n_cand);
+  } else {
+    const int p2 = pow2_at_least(n_cand);
+    for (int t = tid; t < p2; t += nt) sh.sel[t] = t < n_cand ? keys[t] : kKeyEmpty;
+    bitonic_sort_desc<false>(sh.sel, nullptr, p2);
+  }
+  return n_cand < n_candidates ? n_cand : n_candidates;
+}
+
 // Gathers the best n_candidates keys of one query into sh.sel, sorted descending; returns how many
 // are valid.  Two routes:
 //  * sorted lists (the scan's block-merged output: `sorted_lists` lists of n_candidates keys, each
@@ -325,7 +424,7 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(
     const uint64_t* __restrict__ keys_all, int64_t keys_per_query, int sorted_lists, int n_candidates, int k,
     RerankParams rp, const float* __restrict__ dewi32, const float* __restrict__ ent32, int64_t id_offset,
     int64_t* __restrict__ out_ids, float* __restrict__ out_scores, dewi_candidate* __restrict__ out_cand,
-    const uint32_t* __restrict__ counts, SegmentLayout seg) {
+    const uint32_t* __restrict__ counts, SegmentLayout seg, RefineParams refine) {
   __shared__ SelectShared sh;
   const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
   const int q = static_cast<int>(blockIdx.x);
@@ -415,7 +514,18 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(
           }
         }
         __syncthreads();
-        n_sel = top_candidates_lds(dyn_keys, static_cast<int>(total), n_candidates, sh, ws);
+        if (refine.E != nullptr) {
+          n_sel = refine_top_candidates(dyn_keys, static_cast<int>(total), n_candidates, sh, ws, refine, q);
+          if (n_sel == -2) {      // more candidates inside the error band than the sort holds: unanswered, re-run exactly
+            refuse();
+            return;
+          }
+        } else {
+          n_sel = top_candidates_lds(dyn_keys, static_cast<int>(total), n_candidates, sh, ws);
+        }
+      } else if (refine.E != nullptr) {
+        refuse();                 // the refinement works on the staged records only (more than 8192 survivors: adversarial)
+        return;
       } else {
         n_sel = exact_top_candidates(kv, n_candidates, sh);   // more survivors than LDS holds
       }
@@ -765,12 +875,12 @@ hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, 
                                 int n_candidates, int k, const RerankParams& rp, const float* d_dewi32,
                                 const float* d_ent32, int64_t id_offset, int64_t* d_out_ids, float* d_out_scores,
                                 dewi_candidate* d_out_cand, const uint32_t* d_counts, const SegmentLayout& seg,
-                                hipStream_t stream) {
+                                hipStream_t stream, const RefineParams& refine) {
   int threads = kSelectThreads;
   if (sorted_lists > 0) {
     threads = sorted_lists <= 4 * kWave ? 256 : kSelectThreads;  // <= 256 lists: one wave finds the bound
-  } else if (keys_per_query <= 4096 && n_candidates <= 128) {
-    threads = 256;
+  } else if (keys_per_query <= 4096 && n_candidates <= 128 && refine.E == nullptr) {
+    threads = 256;   // (refine mode re-scores its candidates one wave each: sixteen waves)
   }
   size_t dyn = 0;
   if (d_counts != nullptr && seg.lds_keys > 0) {
@@ -784,7 +894,7 @@ hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, 
   }
   hipLaunchKernelGGL(select_rerank_kernel, dim3(n_queries), dim3(threads), dyn, stream, d_keys, keys_per_query,
                      sorted_lists, n_candidates, k, rp, d_dewi32, d_ent32, id_offset, d_out_ids, d_out_scores,
-                     d_out_cand, d_counts, seg);
+                     d_out_cand, d_counts, seg, refine);
   return hipGetLastError();
 }
 

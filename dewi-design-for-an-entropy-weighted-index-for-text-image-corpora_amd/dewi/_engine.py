@@ -341,14 +341,14 @@ class PipelinedSearcher:
         self._scan_done[slot].record(scan_stream)
         self.finish_stream.wait_event(self._scan_done[slot])
         if out_records is None:
-            rc = self._lib.dewi_knn_finish(self._ws[slot].data_ptr(), self._need, self._elem, c.n_rows, c.dim, self.b, self.c,
-                                           self._space, self.k, self.eta, self.pref, self._dewi, self._ent, c.id_offset,
+            rc = self._lib.dewi_knn_finish(self._ws[slot].data_ptr(), self._need, self._emb, self._elem, c.n_rows, c.dim, self.b,
+                                           self.c, self._space, self.k, self.eta, self.pref, self._dewi, self._ent, c.id_offset,
                                            out_ids.data_ptr(), out_scores.data_ptr(), 0, self._s_fin)
             if self.b >= 2:
                 self._written[out_ids.data_ptr()] = (q_dev, out_ids, out_scores)
         else:
-            rc = self._lib.dewi_knn_finish(self._ws[slot].data_ptr(), self._need, self._elem, c.n_rows, c.dim, self.b, self.c,
-                                           self._space, 0, 0.0, 0.0, self._dewi, self._ent, c.id_offset, 0, 0,
+            rc = self._lib.dewi_knn_finish(self._ws[slot].data_ptr(), self._need, self._emb, self._elem, c.n_rows, c.dim, self.b,
+                                           self.c, self._space, 0, 0.0, 0.0, self._dewi, self._ent, c.id_offset, 0, 0,
                                            out_records.data_ptr(), self._s_fin)
         if rc:
             nat.check(rc)
@@ -437,8 +437,9 @@ def prepare_queries_bf16(q_dev, space: str = "cosine"):
 
 def tuning(scan_blocks: int = 0, rows_per_iter: int = 0, nontemporal: int = -1, batched_mfma: int = 1) -> None:
     """Launch-shape overrides of the CALLING THREAD (the library keeps them thread-local).
-    batched_mfma: 0 row kernels only; 1 cosine batches on the matrix cores (default); 2 also ``space="l2"`` batches
-    (2<e,q> - ||e||^2 - ||q||^2: absolute error ~ulp(||e||^2+||q||^2) — near-duplicates of a query lose their
-    near-zero distance; not the parity path)."""
+    batched_mfma: 0 row kernels only; 1 (default) cosine batches on the matrix cores, ``space="l2"`` batches over an fp32
+    corpus too (exact-refine mode: error-widened cut, candidates re-scored with the row kernels' arithmetic); 2 also l2
+    batches over a bf16 corpus, unrefined (2<e,q> - ||e||^2 - ||q||^2: absolute error ~ulp(||e||^2+||q||^2) —
+    near-duplicates of a query lose their near-zero distance; not the parity path)."""
     nat.check(nat.load_library().dewi_tuning_set(int(scan_blocks), int(rows_per_iter), int(nontemporal),
                                                  int(batched_mfma)))

@@ -86,7 +86,7 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.dewi_knn_scan.restype = i32
     lib.dewi_knn_scan.argtypes = [vp, i32, i64, i32, vp, i32, i32, i32, vp, sz, vp]
     lib.dewi_knn_finish.restype = i32
-    lib.dewi_knn_finish.argtypes = [vp, sz, i32, i64, i32, i32, i32, i32, i32, f64, f64, vp, vp, i64, vp, vp, vp, vp]
+    lib.dewi_knn_finish.argtypes = [vp, sz, vp, i32, i64, i32, i32, i32, i32, i32, f64, f64, vp, vp, i64, vp, vp, vp, vp]
     lib.dewi_knn_candidates.restype = i32
     lib.dewi_knn_candidates.argtypes = [vp, i32, i64, i32, vp, i32, vp, vp, i32, i32, i64, vp, vp, sz, vp]
     lib.dewi_merge_rerank.restype = i32

@@ -149,11 +149,12 @@ int dewi_prepare_queries_bf16(const float* d_Q, int n_queries, int dim, int spac
  * k ignored), exactly as dewi_knn_candidates.  elem_type/n_rows/dim/n_queries/n_candidates/space must equal
  * the values given to dewi_knn_scan, and both calls must come from the same host thread's tuning (together
  * they determine the path and the workspace layout).  elem_type: 0 fp32, 1 bf16.  (ABI 3: `space` added.  ABI 4:
- * any n_candidates up to 2^30 — above 2048 the finish step sorts in the workspace, which is therefore no longer const.) */
+ * any n_candidates up to 2^30 — above 2048 the finish step sorts in the workspace, which is therefore no longer const;
+ * d_E, the corpus dewi_knn_scan ran over: an l2 batch over an fp32 corpus re-scores its candidates from the rows.) */
 int dewi_knn_scan(const void* d_E, int elem_type, int64_t n_rows, int dim, const float* d_Q, int n_queries,
                   int n_candidates, int space, void* d_workspace, size_t workspace_bytes, void* stream);
 
-int dewi_knn_finish(void* d_workspace, size_t workspace_bytes, int elem_type, int64_t n_rows, int dim,
+int dewi_knn_finish(void* d_workspace, size_t workspace_bytes, const void* d_E, int elem_type, int64_t n_rows, int dim,
                     int n_queries, int n_candidates, int space, int k, double eta, double entropy_pref,
                     const float* d_dewi32, const float* d_ent32, int64_t id_offset, int64_t* d_out_ids,
                     float* d_out_scores, dewi_candidate* d_out_cand, void* stream);
@@ -265,10 +266,12 @@ int dewi_timing_read(double* out_mean_scan_ms, int* out_launches);
 
 /* Launch-shape overrides for tuning sweeps (0 / -1 = planner default).  batched_mfma = 0 disables the
  * matrix-core paths (every batch then takes the small-batch scan kernels); 1 (default) = cosine batches on the
- * matrix cores, l2 batches on the exact row kernels; 2 = l2 batches on the matrix cores as well, scored as
- * 2<e,q> - ||e||^2 - ||q||^2, whose ABSOLUTE error is ~ulp(||e||^2 + ||q||^2) where the reference's
- * -sum((e-q)^2) (backends.py:434-436) has a relative error of the distance: near-duplicates of a query then score
- * +-1e-4 instead of ~0 at ||e||^2 ~ 500 (an opt-in for throughput, not the parity path).  The setting belongs to the
+ * matrix cores; l2 batches over an fp32 corpus too, in exact-refine mode (the pass scores 2<e,q> - ||e||^2 - ||q||^2,
+ * whose ABSOLUTE error is ~ulp(||e||^2 + ||q||^2) where the reference's -sum((e-q)^2), backends.py:434-436, has a
+ * relative error of the distance; the candidate cut is widened by that bound and the candidates are re-scored with the
+ * row kernels' arithmetic, so results equal the one-query search bit for bit); l2 batches over a bf16 corpus on the
+ * exact row kernels; 2 = those on the matrix cores as well, WITHOUT refinement (near-duplicates of a query then score
+ * +-1e-4 instead of ~0 at ||e||^2 ~ 500: an opt-in for throughput, not the parity path).  The setting belongs to the
  * CALLING THREAD (thread-local): it changes the plan, and with it dewi_knn_workspace_bytes, only for calls
  * made from the same thread, so one thread's sweep cannot invalidate another thread's workspace. */
 int dewi_tuning_set(int scan_blocks, int rows_per_iter, int nontemporal, int batched_mfma);

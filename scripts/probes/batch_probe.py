@@ -37,8 +37,8 @@ c = eng.DeviceCorpus(emb, torch.rand(n, device=dev), torch.rand(n, device=dev), 
 if bf16:
     c = c.to_bf16()
     del emb
-if space == "l2":
-    eng.tuning(0, 0, -1, 2)      # l2 on the matrix cores is opt-in (default: exact row kernels)
+if space == "l2" and bf16:
+    eng.tuning(0, 0, -1, 2)      # l2 over a bf16 corpus on the matrix cores is an opt-in (default: exact row kernels)
 elem = 2 if bf16 else 4
 args = [a for a in args if a not in ("--graph", "--split")]
 sizes = [int(a) for a in args] or [8, 32, 64, 256]
@@ -85,7 +85,7 @@ for b in sizes:
         def scan(i):
             nat.check(lib.dewi_knn_scan(nat.ptr(c.emb), et, n, d, nat.ptr(Q[i % 8]), b, cc, sp, nat.ptr(ws), need, nat.stream_ptr()))
         def fin():
-            nat.check(lib.dewi_knn_finish(nat.ptr(ws), need, et, n, d, b, cc, sp, k, 0.3, 0.0, nat.ptr(c.dewi32), nat.ptr(c.ent32), 0,
+            nat.check(lib.dewi_knn_finish(nat.ptr(ws), need, nat.ptr(c.emb), et, n, d, b, cc, sp, k, 0.3, 0.0, nat.ptr(c.dewi32), nat.ptr(c.ent32), 0,
                                           nat.ptr(oi), nat.ptr(osc), 0, nat.stream_ptr()))
         for what, fn in (("scan", scan), ("finish", lambda i: fin()), ("scan+finish", lambda i: (scan(i), fin()))):
             for i in range(5):

@@ -127,13 +127,51 @@ def test_large_merge_carries_the_refusal_marker_and_rejects_a_short_workspace():
     assert rc == nat.ERR_WORKSPACE and "workspace" in nat.last_error()
 
 
+@pytest.mark.parametrize("dim,k,b,qscale", [(768, 10, 33, 1.0), (512, 50, 8, 1.0), (256, 128, 40, 1.0), (768, 10, 12, 20.0)])
+def test_l2_exact_refine_equals_the_one_query_search(dim, k, b, qscale):
+    """l2 batches over an fp32 corpus run on the matrix cores in exact-refine mode: the pass's score has an absolute error
+    bound, the candidate cut is widened by it and the candidates are re-scored with the row kernels' arithmetic — so a
+    batch must equal the one-query searches BIT FOR BIT (ids and scores), whatever the norms (qscale 20: ||q||^2 ~ 300 000,
+    where the unrefined matrix-core score is off by ~0.05), at every supported dim, and agree with the oracle."""
+    import torch
+    eng = _engine()
+    n = 66_000 + dim
+    rng = np.random.default_rng(dim + k)
+    raw = orc.synth_corpus(n, dim, seed=dim + k) * rng.uniform(0.5, 4.0, size=(n, 1)).astype(np.float32)
+    Q = (orc.synth_queries(b, dim, seed=k) * rng.uniform(0.5, 2.0, size=(b, 1)) * qscale).astype(np.float32)
+    Q[0] = raw[123]                                                   # an exact duplicate
+    cols = orc.synth_payload_columns(n, seed=dim)
+    c = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"], space="l2")
+    dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    ids, sc = c.search(Q, k, 0.3, 0.1)
+    assert ids.min() >= 0
+    for j in range(b):
+        i1, s1 = c.search(Q[j], k, 0.3, 0.1)
+        assert np.array_equal(ids[j], i1[0]) and np.array_equal(sc[j], s1[0]), j
+    assert ids[0][0] == 123 or 123 in ids[0]
+    check = list(range(0, b, max(1, b // 8)))
+    for j in check:
+        _, msg = compare_query(raw, Q[j], dewi32, ent32, k, 0.3, 0.1, "l2", ids[j], sc[j], exact_gaps=False)
+        assert msg is None, (j, msg)
+    # shard records through the same mode: candidates + merge == whole
+    qd = torch.from_numpy(Q).cuda()
+    cc = 2 * k
+    recs = c.candidates_device(qd, cc)
+    m_ids, m_sc = (t.cpu().numpy() for t in eng.merge_rerank_device(recs.unsqueeze(0), cc, k, 0.3, 0.1))
+    answered = m_ids[:, 0] >= 0          # (at qscale 20 the error band holds more candidates than the sort: such a query is
+    assert np.all(m_ids[~answered] == -1)   # REFUSED — records id -2, merge id -1 — and `search` re-ran it on the row kernels)
+    assert np.array_equal(m_ids[answered], ids[answered]) and np.array_equal(m_sc[answered], sc[answered])
+    assert answered.all() or qscale > 1.0
+
+
 @pytest.mark.parametrize("bf16", [False, True])
 def test_l2_batches_keep_near_duplicates_at_zero_distance(bf16):
     """The default l2 batch path must give what the reference's -sum((E - q)^2) gives (backends.py:434-436) where it
     matters most: queries that are (near-)duplicates of corpus rows with large norms.  On the matrix cores the score
-    2<e,q> - ||e||^2 - ||q||^2 would come back as +-1e-4 noise at ||e||^2 ~ 500 — so by default an l2 batch takes the
-    exact row kernels: search_batch(Q)[j] == search(Q[j]) bit for bit, the duplicate's score is the reference's to the
-    UNSCALED 1e-5 of north_star, and ranking among near neighbours follows the oracle."""
+    2<e,q> - ||e||^2 - ||q||^2 comes back as +-1e-4 noise at ||e||^2 ~ 500 — so over an fp32 corpus the pass runs in
+    exact-refine mode (error-widened cut, candidates re-scored with the row kernels' arithmetic) and over a bf16 corpus
+    the batch takes the exact row kernels: either way search_batch(Q)[j] == search(Q[j]) bit for bit, the duplicate's
+    score is the reference's to the UNSCALED 1e-5 of north_star, and ranking among near neighbours follows the oracle."""
     import torch
     eng = _engine()
     n, d, b, k = 70_000, 256, 12, 10
