@@ -273,6 +273,11 @@ def run_c2(args, torch, dist, eng, nat, rank, world, device):
     corpus = eng.DeviceCorpus(emb_raw, dewi32, ent32, "cosine", id_offset=lo)
     n_q = args.warmup + args.steps
     B = args.batch
+    shadowed = B > 32 and world == 1 and args.dim in (256, 512, 768)
+    if shadowed:
+        # batches of more than 32 queries over the fp32 corpus: 256-query pass over a bf16 shadow copy as a pre-selection,
+        # candidates re-scored from the fp32 rows (dewi_knn_rerank_f32_shadow): fp32-exact results, +50 % memory
+        corpus.enable_bf16_shadow()
     qg = torch.Generator(device=device)
     qg.manual_seed(7)
     n_cpu = max(50, args.cpu_queries) if args.cpu_queries > 0 else 0
@@ -425,11 +430,13 @@ def run_c2(args, torch, dist, eng, nat, rank, world, device):
 
     qps = args.steps * B / elapsed
     ms_per_step = elapsed / args.steps * 1e3
-    elem = corpus.emb.element_size()
-    algo_bytes = n_local * args.dim * elem + B * args.dim * 4           # per scan launch, this rank
+    elem = 2 if shadowed else corpus.emb.element_size()              # the dominant pass streams the bf16 shadow
+    algo_bytes = n_local * args.dim * elem + B * args.dim * (2 if shadowed else 4)           # per scan launch, this rank
     achieved = algo_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-    # --batch >= 5 over the fp32 corpus: the depth-split matrix-core pass is the dominant kernel (one per 32 queries)
-    kernel = "scan_rows_f32" if B < 5 else f"mfma_scan_f32<false,{args.dim // 256},false,false>"
+    # --batch >= 5 over the fp32 corpus: the depth-split matrix-core pass is the dominant kernel (one per 32 queries);
+    # --batch > 32: the 256-query pass over the bf16 shadow (one per 256 queries)
+    kernel = ("scan_rows_f32" if B < 5 else f"mfma_scan_f32<false,{args.dim // 256},false,false>" if not shadowed
+              else f"mfma_scan_bf16_s16<{args.dim // 16},false>")
     traffic, traffic_note = recorded_traffic(f"{n_local}x{args.dim}x{elem}xB{B}", kernel)
 
     result = {
@@ -451,6 +458,7 @@ def run_c2(args, torch, dist, eng, nat, rank, world, device):
                    "parallelism": (f"doc-id shards x{world} + RCCL all-gather" if not sharded or dist.get_backend() == "nccl" else
                                    f"REHEARSAL: {world} ranks on shared GPUs, records staged through the host ({dist.get_backend()})")
                    if sharded else "single GPU",
+                   "bf16_shadow": shadowed,
                    "queries_in_flight": 1 if (serial and not sharded) else (3 * G if sharded else 2),
                    "rows_per_gpu": n_local, "conditioning_steps_before_warmup": n_condition},
         "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,

@@ -269,7 +269,7 @@ int batch_scan(const BatchPlan& P, const void* d_E, int elem_type, int64_t n_row
 int batch_select(const BatchPlan& P, void* d_ws, size_t ws_bytes, int n_queries, int n_candidates, int k,
                  const dewi::RerankParams& rp, const float* d_dewi32, const float* d_ent32, int64_t id_offset,
                  int64_t* d_out_ids, float* d_out_scores, dewi_candidate* d_out_cand, hipStream_t stream,
-                 const void* d_E, int elem_type, int dim, int space) {
+                 const void* d_E, int elem_type, int dim, int space, const float* d_Q_shadow = nullptr) {
   if (!d_ws || ws_bytes < P.total) return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, P.total);
   char* ws = static_cast<char*>(d_ws);
   hipError_t e = hipSuccess;
@@ -300,19 +300,30 @@ int batch_select(const BatchPlan& P, void* d_ws, size_t ws_bytes, int n_queries,
   const int seg_cap = big ? P.big.seg_cap : P.depth.seg_cap;
   const size_t cand_off = big ? P.big.cand_off : P.depth.cand_off, cnt_off = big ? P.big.cnt_off : P.depth.cnt_off;
   // counts: query-major for the 256-query pass (coalesced in the select kernel), segment-major for the depth-split pass
-  const dewi::SegmentLayout seg{n_seg, seg_cap, 1, static_cast<int64_t>(per) * seg_cap, big ? 1 : per, 8192, big ? n_seg : 1};
-  const bool refine = !big && space == DEWI_SPACE_L2 && elem_type == 0;
+  // (LDS staging of a query's survivors: 8192 records; 12288 when the scores only pre-select for the exact re-scoring of
+  // an fp32 corpus — its thresholds sit two error bounds lower, ~10 K survivors per query at k = 100)
+  const dewi::SegmentLayout seg{n_seg, seg_cap, 1, static_cast<int64_t>(per) * seg_cap, big ? 1 : per,
+                                (big && d_Q_shadow != nullptr) ? 12288 : 8192, big ? n_seg : 1};
+  // exact-refine modes: l2 on the depth-split pass over an fp32 corpus (queries and norms as the scan left them in the
+  // workspace), or the 256-query pass over the bf16 SHADOW of an fp32 corpus (d_Q_shadow = the caller's raw queries)
+  const bool refine_l2 = !big && space == DEWI_SPACE_L2 && elem_type == 0;
+  const bool refine_shadow = big && d_Q_shadow != nullptr;
+  const bool refine = refine_l2 || refine_shadow;
   if (refine && !d_E) return fail(DEWI_ERR_INVALID_ARG, "l2 over an fp32 corpus: the finish step needs the corpus pointer");
   for (int g = 0; g < groups && e == hipSuccess; ++g) {
     const int q0 = g * per;
     const int nq = n_queries - q0 < per ? n_queries - q0 : per;
     const uint64_t* keys = reinterpret_cast<const uint64_t*>(ws + cand_off) + static_cast<int64_t>(g) * n_seg * per * seg_cap;
     const uint32_t* counts = reinterpret_cast<const uint32_t*>(ws + cnt_off) + static_cast<int64_t>(g) * n_seg * per;
-    dewi::RefineParams rf{nullptr, nullptr, nullptr, 0, 0.f};
-    if (refine)   // the raw queries and their squared norms as the scan left them in the workspace
+    dewi::RefineParams rf{nullptr, nullptr, nullptr, 0, 0.f, 0};
+    if (refine_l2)   // the raw queries and their squared norms as the scan left them in the workspace
       rf = dewi::RefineParams{static_cast<const float*>(d_E),
                               reinterpret_cast<const float*>(ws + P.depth.qn_off) + static_cast<int64_t>(q0) * dim,
-                              reinterpret_cast<const float*>(ws + P.depth.qn2_off) + q0, dim, dewi::depth_l2_margin(dim)};
+                              reinterpret_cast<const float*>(ws + P.depth.qn2_off) + q0, dim, dewi::depth_l2_margin(dim),
+                              DEWI_SPACE_L2};
+    else if (refine_shadow)
+      rf = dewi::RefineParams{static_cast<const float*>(d_E), d_Q_shadow + static_cast<int64_t>(q0) * dim, nullptr, dim,
+                              dewi::shadow_margin(dim), DEWI_SPACE_COSINE};
     e = dewi::launch_select_rerank(keys, 0, 0, nq, n_candidates, k, rp, d_dewi32, d_ent32, id_offset,
                                    d_out_ids ? d_out_ids + static_cast<int64_t>(q0) * k : nullptr,
                                    d_out_scores ? d_out_scores + static_cast<int64_t>(q0) * k : nullptr,
@@ -431,6 +442,42 @@ int dewi_knn_rerank_f32(const float* d_E, int64_t n_rows, int dim, const float* 
                         void* stream) {
   return knn_rerank_impl(d_E, 0, n_rows, dim, d_Q, n_queries, d_dewi32, d_ent32, k, eta, entropy_pref, space,
                          d_out_ids, d_out_scores, d_workspace, workspace_bytes, stream);
+}
+
+int dewi_knn_rerank_f32_shadow(const float* d_E, const uint16_t* d_E_bf16, int64_t n_rows, int dim, const float* d_Q,
+                               int n_queries, const float* d_dewi32, const float* d_ent32, int k, double eta,
+                               double entropy_pref, int space, int64_t* d_out_ids, float* d_out_scores, void* d_workspace,
+                               size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  int rc = check_common(d_E, n_rows, dim, d_Q, n_queries, space);
+  if (rc) return rc;
+  DeviceInfo dev;
+  rc = ensure_device(dev);
+  if (rc) return rc;
+  const int64_t c64 = (2ll * k < n_rows) ? 2ll * k : n_rows;
+  // the shadow pre-selects only where the 256-query pass runs and the one-query search of the same corpus takes the
+  // row-per-wave kernel whose arithmetic the refinement repeats (dim 256 / 512 / 768); everything else is the plain search
+  const bool use = d_E_bf16 != nullptr && g_tuning.mfma != 0 && space == DEWI_SPACE_COSINE && n_queries > 32 && k > 0 &&
+                   k <= n_rows && (dim == 256 || dim == 512 || dim == 768) && c64 <= dewi::kMaxSortCandidates &&
+                   dewi::mfma_path_supported(n_rows, dim, n_queries, static_cast<int>(c64), space);
+  if (!use)
+    return knn_rerank_impl(d_E, 0, n_rows, dim, d_Q, n_queries, d_dewi32, d_ent32, k, eta, entropy_pref, space, d_out_ids,
+                           d_out_scores, d_workspace, workspace_bytes, stream_);
+  if (!d_dewi32 || !d_ent32 || !d_out_ids || !d_out_scores) return fail(DEWI_ERR_INVALID_ARG, "null payload or output pointer");
+  const int c = static_cast<int>(c64);
+  BatchPlan P{};
+  P.path = BatchPath::Big;
+  P.c_local = c;
+  P.big = dewi::plan_mfma(n_rows, dim, n_queries, c, dev.cus);
+  P.total = P.big.total;
+  if (!d_workspace || workspace_bytes < P.total) return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, P.total);
+  // scores from bf16(e), bf16(q) are within shadow_margin of the fp32 row kernels': the sample's c-th best minus the bound is
+  // a lower bound of the exact c-th best, and a row may score that much lower here than exactly -> thresholds - 2 bounds
+  hipError_t e = dewi::launch_mfma_bf16(P.big, d_E_bf16, n_rows, dim, d_Q, n_queries, c, space, static_cast<char*>(d_workspace),
+                                        dev.cus, stream, 2.f * dewi::shadow_margin(dim));
+  if (e != hipSuccess) return hip_fail(e, "mfma scan launch (bf16 shadow)");
+  return batch_select(P, d_workspace, workspace_bytes, n_queries, c, k, make_rerank(eta, entropy_pref, DEWI_SIM_RAW, space), d_dewi32,
+                      d_ent32, 0, d_out_ids, d_out_scores, nullptr, stream, d_E, 0, dim, space, d_Q);
 }
 
 int dewi_knn_rerank_candidates(const void* d_E, int elem_type, int64_t n_rows, int dim, const float* d_Q, int n_queries,

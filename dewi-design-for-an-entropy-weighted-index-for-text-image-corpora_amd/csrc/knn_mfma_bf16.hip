@@ -200,7 +200,7 @@ template <int KS, bool DENSE>
 __global__ __launch_bounds__(512, 2) void mfma_scan_bf16_s16(
     const uint16_t* __restrict__ E, int64_t n_rows, const uint16_t* __restrict__ Qb, int64_t n_tiles,
     int64_t tile_stride, const float* __restrict__ thr, uint64_t* __restrict__ out, int64_t out_stride,
-    uint32_t* __restrict__ cnt, int n_active) {
+    uint32_t* __restrict__ cnt, int n_active, float thr_bias) {
   // DENSE (sample pass): out is a float array: out[q * out_stride + (4 * blockIdx.x + g) * 8 + 4 dh + t] = the best score
   //        that accumulator register saw over this workgroup's (strided) tiles — 32 group maxima per workgroup and query.
   // filter: raw records out[((4 * blockIdx.x + g) * 256 + q) * out_stride + slot], cnt[q * 4 gridDim.x + 4 * blockIdx.x + g].
@@ -235,7 +235,9 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_bf16_s16(
 #pragma unroll
   for (int qh = 0; qh < 2; ++qh) {
     const int q = 32 * wave + 16 * qh + c;
-    thr_l[qh] = DENSE ? -__builtin_inff() : (q < n_active ? thr[q] : __builtin_inff());
+    // thr_bias: 0, or twice the error bound of these scores when they only PRE-SELECT for an exact re-scoring (an fp32
+    // corpus scanned through its bf16 shadow: launch.hpp, shadow_margin)
+    thr_l[qh] = DENSE ? -__builtin_inff() : (q < n_active ? thr[q] - thr_bias : __builtin_inff());
   }
 #pragma unroll
   for (int s = 0; s < KS2; ++s) {
@@ -650,6 +652,11 @@ __global__ __launch_bounds__(kSelectThreads) void sample_threshold_kernel(const 
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+// |<e,q> computed from bf16(e), bf16(q) on the matrix cores - <e,q> computed by the fp32 row kernels| for rows and queries
+// of norm <= 1.0001: bf16 rounding (2^-9 relative per factor: (1 + 2^-9)^2 - 1 of sum |e_i q_i| <= ||e|| ||q||), dim fp32
+// accumulations here (2^-23 each, conservatively) and dim there (2^-24).
+float shadow_margin(int dim) { return (0.00390625f * 1.002f + 1.5f * static_cast<float>(dim) * 1.1920929e-7f) * 1.0003f; }
+
 bool mfma_path_supported(int64_t n_rows, int dim, int n_queries, int n_candidates, int space) {
   return space == DEWI_SPACE_COSINE && n_queries >= kMfmaMinQueries && dim % 128 == 0 && dim <= 768 &&
          n_rows >= 64 * 1024 && n_candidates <= kMaxSortCandidates &&
@@ -703,7 +710,7 @@ hipError_t launch_sample_threshold(const float* dense, int64_t n_sample, int64_t
 }
 
 using ScanKernel = void (*)(const uint16_t*, int64_t, const uint16_t*, int64_t, int64_t, const float*, uint64_t*, int64_t, uint32_t*,
-                            int);
+                            int, float);
 template <int KS, bool DENSE>
 static ScanKernel scan_kernel() {
   return &mfma_scan_bf16_s16<KS, DENSE>;
@@ -711,7 +718,7 @@ static ScanKernel scan_kernel() {
 
 template <int KS>
 static hipError_t run_mfma_dim(const MfmaLayout& m, const uint16_t* E, int64_t n_rows, int n_queries, int n_candidates,
-                               char* ws, int compute_units, hipStream_t stream) {
+                               char* ws, int compute_units, hipStream_t stream, float thr_bias) {
   constexpr int DIM = KS * 16;
   const int lds_bytes = kTileBufs * kTileRows * DIM * 2;
   static PerDeviceOnce attr_once;   // one per KS instantiation
@@ -739,7 +746,7 @@ static hipError_t run_mfma_dim(const MfmaLayout& m, const uint16_t* E, int64_t n
     const ScanKernel k_sample = scan_kernel<KS, true>(), k_filter = scan_kernel<KS, false>();
     hipLaunchKernelGGL(k_sample, dim3(sample_blocks), dim3(kMfmaThreads), lds_bytes, stream, E, n_rows,
                        qg, m.n_sample_tiles, static_cast<int64_t>(kSampleStride), static_cast<const float*>(nullptr),
-                       reinterpret_cast<uint64_t*>(dense), m.sample_stride, static_cast<uint32_t*>(nullptr), n_active);
+                       reinterpret_cast<uint64_t*>(dense), m.sample_stride, static_cast<uint32_t*>(nullptr), n_active, 0.f);
     // 2. per-query threshold (real queries only: a padding query's sample scores are all equal, which is the
     //    worst case of the histogram select, and its threshold is not used)
     const hipError_t et = launch_sample_threshold(dense, m.sample_stride, m.sample_stride, n_candidates, tg, n_active, stream);
@@ -749,7 +756,7 @@ static hipError_t run_mfma_dim(const MfmaLayout& m, const uint16_t* E, int64_t n
     timing_begin(stream);
     hipLaunchKernelGGL(k_filter, dim3(m.n_blocks), dim3(kMfmaThreads), lds_bytes, stream, E, n_rows, qg,
                        m.n_tiles, static_cast<int64_t>(1), static_cast<const float*>(tg), og,
-                       static_cast<int64_t>(m.seg_cap), cg, n_active);
+                       static_cast<int64_t>(m.seg_cap), cg, n_active, thr_bias);
     timing_end(stream);
   }
   return hipGetLastError();
@@ -763,19 +770,19 @@ hipError_t launch_prepare_queries_bf16(const float* d_Q, uint16_t* d_out, int n_
 
 hipError_t launch_mfma_bf16(const MfmaLayout& m, const uint16_t* d_E, int64_t n_rows, int dim, const float* d_Q,
                             int n_queries, int n_candidates, int space, char* ws, int compute_units,
-                            hipStream_t stream) {
+                            hipStream_t stream, float thr_bias) {
   // one launch per group of 256 would index rows from 0: the image of group g starts at g * 256 * dim, and the
   // fragment order is relative to the group's first query — (q / 32) etc. of the GLOBAL row index differ from the
   // group-local ones only by whole groups of 256 rows = 256 * dim elements, which is exactly the group's offset
   hipLaunchKernelGGL(prepare_queries_bf16, dim3(m.q_pad), dim3(kWave), 0, stream, d_Q,
                      reinterpret_cast<uint16_t*>(ws + m.qb_off), n_queries, dim, space, static_cast<float*>(nullptr), 1);
   switch (dim / 16) {
-    case 8: return run_mfma_dim<8>(m, d_E, n_rows, n_queries, n_candidates, ws, compute_units, stream);
-    case 16: return run_mfma_dim<16>(m, d_E, n_rows, n_queries, n_candidates, ws, compute_units, stream);
-    case 24: return run_mfma_dim<24>(m, d_E, n_rows, n_queries, n_candidates, ws, compute_units, stream);
-    case 32: return run_mfma_dim<32>(m, d_E, n_rows, n_queries, n_candidates, ws, compute_units, stream);
-    case 40: return run_mfma_dim<40>(m, d_E, n_rows, n_queries, n_candidates, ws, compute_units, stream);
-    case 48: return run_mfma_dim<48>(m, d_E, n_rows, n_queries, n_candidates, ws, compute_units, stream);
+    case 8: return run_mfma_dim<8>(m, d_E, n_rows, n_queries, n_candidates, ws, compute_units, stream, thr_bias);
+    case 16: return run_mfma_dim<16>(m, d_E, n_rows, n_queries, n_candidates, ws, compute_units, stream, thr_bias);
+    case 24: return run_mfma_dim<24>(m, d_E, n_rows, n_queries, n_candidates, ws, compute_units, stream, thr_bias);
+    case 32: return run_mfma_dim<32>(m, d_E, n_rows, n_queries, n_candidates, ws, compute_units, stream, thr_bias);
+    case 40: return run_mfma_dim<40>(m, d_E, n_rows, n_queries, n_candidates, ws, compute_units, stream, thr_bias);
+    case 48: return run_mfma_dim<48>(m, d_E, n_rows, n_queries, n_candidates, ws, compute_units, stream, thr_bias);
     default: return hipErrorInvalidValue;
   }
 }

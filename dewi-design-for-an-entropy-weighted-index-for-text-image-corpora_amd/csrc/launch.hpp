@@ -113,9 +113,12 @@ hipError_t launch_prepare_queries_bf16(const float* d_Q, uint16_t* d_out, int n_
 bool mfma_path_supported(int64_t n_rows, int dim, int n_queries, int n_candidates, int space);
 MfmaLayout plan_mfma(int64_t n_rows, int dim, int n_queries, int n_candidates, int compute_units);
 // Fills cand keys [groups][n_seg][256][seg_cap] and counts [groups][256][n_seg] in the workspace.
+// thr_bias: subtracted from every query's threshold in the filter pass (0: exact scores; 2 * shadow_margin(dim): the
+// scores pre-select for an exact re-scoring of an fp32 corpus)
 hipError_t launch_mfma_bf16(const MfmaLayout& m, const uint16_t* d_E, int64_t n_rows, int dim, const float* d_Q,
                             int n_queries, int n_candidates, int space, char* ws, int compute_units,
-                            hipStream_t stream);
+                            hipStream_t stream, float thr_bias = 0.f);
+float shadow_margin(int dim);
 
 // ---- knn_mfma_f32.hip: batched (32 queries per corpus pass) fp32 path on the matrix cores
 constexpr int kMfmaF32MinQueries = 5;  // fp32 corpus: batches of at least this many queries take the matrix-core path
@@ -177,16 +180,17 @@ struct SegmentLayout {
 // select kernel widens the candidate cut by the error bound and re-scores the candidates with the row kernels' arithmetic.
 struct RefineParams {
   const float* E;        // corpus rows [n_rows][dim] fp32 (NULL: off)
-  const float* Q;        // this launch's queries [n_queries][dim] fp32, as the scan used them (l2: raw)
-  const float* qn2;      // ||q||^2 per query
-  int dim;
-  float margin;          // depth_l2_margin(dim)
+  const float* Q;        // this launch's RAW queries [n_queries][dim] fp32 (cosine: normalised here as the row kernels do)
+  const float* qn2;      // l2: ||q||^2 per query
+  int dim;               // 256, 512 or 768
+  float margin;          // l2: depth_l2_margin(dim), the bound per unit of ||e||^2 + ||q||^2; cosine: the bound itself
+  int space;             // DEWI_SPACE_*
 };
 hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, int sorted_lists, int n_queries,
                                 int n_candidates, int k, const RerankParams& rp, const float* d_dewi32, const float* d_ent32,
                                 int64_t id_offset, int64_t* d_out_ids, float* d_out_scores,
                                 dewi_candidate* d_out_cand, const uint32_t* d_counts, const SegmentLayout& seg,
-                                hipStream_t stream, const RefineParams& refine = RefineParams{nullptr, nullptr, nullptr, 0, 0.f});
+                                hipStream_t stream, const RefineParams& refine = RefineParams{nullptr, nullptr, nullptr, 0, 0.f, 0});
 // c > kMaxSortCandidates: dense keys [n_queries][keys_per_query] in, scratch g1/g2 [n_queries][p2].
 // d_out_cand != NULL: n_out records per query (the shard's candidates) instead of final results.
 hipError_t launch_select_rerank_large(const uint64_t* d_keys, int64_t keys_per_query, int n_queries, int n_candidates,

@@ -167,31 +167,35 @@ __device__ int top_candidates_lds(const uint64_t* keys, int n, int n_candidates,
   return n_sel;
 }
 
-// EXACT REFINEMENT of approximate survivor scores (space l2 on the matrix cores over an fp32 corpus, RefineParams).
-// `keys` (dense LDS array, n unique keys) carry the matrix-core scores a = 2<e,q> - ||e||^2 - ||q||^2, each within
-//     M(a) = margin * (3 ||q||^2 + 2 d) * 1.01,   d = max(0, -a)
-// of the row's exact score: the kernel's bound is margin * (||e||^2 + ||q||^2), and ||e|| <= ||q|| + sqrt(d_exact) gives
-// ||e||^2 + ||q||^2 <= 3 ||q||^2 + 2 d_exact (the 1 % covers d_exact vs d).  Steps:
+// EXACT REFINEMENT of approximate survivor scores (RefineParams).  Two producers:
+//   l2      the depth-split pass over an fp32 corpus: a = 2<e,q> - ||e||^2 - ||q||^2, within
+//           M(a) = margin * (3 ||q||^2 + 2 d) * 1.01,   d = max(0, -a)
+//           of the row's exact score (the kernel's bound is margin * (||e||^2 + ||q||^2), and ||e|| <= ||q|| + sqrt(d_exact)
+//           gives ||e||^2 + ||q||^2 <= 3 ||q||^2 + 2 d_exact; the 1 % covers d_exact vs d);
+//   cosine  the 256-query bf16 pass over the bf16 SHADOW of an fp32 corpus: a = <bf16(e), bf16(q)>, within the constant
+//           M = margin (launch.hpp shadow_margin) of the fp32 row kernel's <e, q>.
+// `keys` (dense LDS array, n unique keys) carry those scores.  Steps:
 //   1. a_c = the c-th largest approximate score (radix select as before); L = a_c - M(a_c) is a lower bound of the c-th
-//      best EXACT score (c rows have exact >= a - M(a) >= L, M growing with d);
-//   2. every key with a + M(a) >= L is a candidate (c' >= c of them; usually c plus a handful) — no row of the exact
-//      top c can be missing;
-//   3. one wave per candidate re-scores it with THE ROW KERNEL'S ARITHMETIC (scan_rows_f32<U, ..., l2>: lane l takes the
-//      16-byte units l + 64 u, u ascending, d = e - q, fmaf(d, d, acc); wave_sum_f32; negate), so the score — and with it
-//      the ranking — is bit for bit what the one-query search computes for that row (dim = 256 U);
+//      best EXACT score (c rows have exact >= a - M(a) >= L, M not shrinking as a falls);
+//   2. every key with a + M(a) >= L is a candidate (c' >= c of them) — no row of the exact top c can be missing;
+//   3. one wave per candidate re-scores it with THE ROW KERNEL'S ARITHMETIC (scan_rows_f32<U, ...>: lane l takes the
+//      16-byte units l + 64 u, u ascending; cosine: the query normalised by the float64-summed norm, fmaf(e, q, acc);
+//      l2: d = e - q, fmaf(d, d, acc), negated; wave_sum_f32), so the score — and with it the ranking — is bit for bit
+//      what the one-query search computes for that row (dim = 256 U, U <= 3);
 //   4. the exact keys are sorted, the best c stay in sh.sel.
-// Returns the number of valid keys in sh.sel, or -2 when more candidates qualify than sh.sel2 holds (adversarial: the
-// query is refused and the caller re-runs it on the row kernels).  `tmp`: at least kMaxSortCandidates keys of scratch
-// that is not `keys`... it IS `keys`: the dense array is dead once the candidates are compacted.
+// Returns the number of valid keys in sh.sel, or -2 when more candidates qualify than sh.sel2 holds (the query is
+// refused and the caller re-runs it on the row kernels).  The dense array doubles as scratch once the candidates are
+// compacted.
 __device__ __forceinline__ int refine_top_candidates(uint64_t* keys, int n, int n_candidates, SelectShared& sh,
                                                      WideRadixShared& ws, const RefineParams& rf, int q) {
   const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
   const int lane = tid & 63, wave = tid >> 6, n_waves = nt >> 6;
   const uint64_t thr = block_kth_largest_lds(keys, n, static_cast<uint32_t>(n_candidates), ws);
-  const float q2 = rf.qn2[q];
+  const bool l2 = rf.space == DEWI_SPACE_L2;
+  const float q2 = l2 ? rf.qn2[q] : 0.f;
   auto bound = [&](float a) {                      // M(a); NaN scores (NaN rows rank first) get an infinite bound
     const float d = a < 0.f ? -a : 0.f;
-    return a == a ? rf.margin * (3.f * q2 + 2.f * d) * 1.01f : __builtin_inff();
+    return a == a ? (l2 ? rf.margin * (3.f * q2 + 2.f * d) * 1.01f : rf.margin) : __builtin_inff();
   };
   float low = -__builtin_inff();                   // fewer than c keys: every key is a candidate
   if (thr != 1ull) {
@@ -227,6 +231,22 @@ __device__ __forceinline__ int refine_top_candidates(uint64_t* keys, int n, int 
   f32x4r qv[kMaxUnits];
 #pragma unroll
   for (int u = 0; u < kMaxUnits; ++u) qv[u] = u < units ? qp[u * 64] : f32x4r{0.f, 0.f, 0.f, 0.f};
+  if (!l2) {   // cosine: the prepared query of scan_rows_f32 — float64 sum of squares in its order, one norm, __fdiv_rn
+    double ss = 0.0;
+#pragma unroll
+    for (int u = 0; u < kMaxUnits; ++u)
+      if (u < units) ss += square_f64(qv[u].x) + square_f64(qv[u].y) + square_f64(qv[u].z) + square_f64(qv[u].w);
+    const float norm = wave_query_norm(ss);
+    if (norm > 0.f) {
+#pragma unroll
+      for (int u = 0; u < kMaxUnits; ++u) {
+        qv[u].x = __fdiv_rn(qv[u].x, norm);
+        qv[u].y = __fdiv_rn(qv[u].y, norm);
+        qv[u].z = __fdiv_rn(qv[u].z, norm);
+        qv[u].w = __fdiv_rn(qv[u].w, norm);
+      }
+    }
+  }
   for (int t0 = wave * kBatch; t0 < n_cand; t0 += n_waves * kBatch) {
     f32x4r e[kBatch][kMaxUnits];
     uint32_t rows[kBatch];
@@ -242,16 +262,24 @@ __device__ __forceinline__ int refine_top_candidates(uint64_t* keys, int n, int 
     for (int bb = 0; bb < kBatch; ++bb) {
       float acc = 0.f;
 #pragma unroll
-      for (int u = 0; u < kMaxUnits; ++u) {         // u ascending, x y z w: scan_rows_f32's accum4<l2>.  Unrolled with a
+      for (int u = 0; u < kMaxUnits; ++u) {         // u ascending, x y z w: scan_rows_f32's accum4.  Unrolled with a
         if (u < units) {                            // uniform guard: a run-time index would put e[][] into scratch memory
-          float d;
-          d = e[bb][u].x - qv[u].x; acc = __builtin_fmaf(d, d, acc);
-          d = e[bb][u].y - qv[u].y; acc = __builtin_fmaf(d, d, acc);
-          d = e[bb][u].z - qv[u].z; acc = __builtin_fmaf(d, d, acc);
-          d = e[bb][u].w - qv[u].w; acc = __builtin_fmaf(d, d, acc);
+          if (l2) {
+            float d;
+            d = e[bb][u].x - qv[u].x; acc = __builtin_fmaf(d, d, acc);
+            d = e[bb][u].y - qv[u].y; acc = __builtin_fmaf(d, d, acc);
+            d = e[bb][u].z - qv[u].z; acc = __builtin_fmaf(d, d, acc);
+            d = e[bb][u].w - qv[u].w; acc = __builtin_fmaf(d, d, acc);
+          } else {                                  // accum4<cosine>
+            acc = __builtin_fmaf(e[bb][u].x, qv[u].x, acc);
+            acc = __builtin_fmaf(e[bb][u].y, qv[u].y, acc);
+            acc = __builtin_fmaf(e[bb][u].z, qv[u].z, acc);
+            acc = __builtin_fmaf(e[bb][u].w, qv[u].w, acc);
+          }
         }
       }
-      const float sc = -wave_sum_f32(acc);
+      const float sum = wave_sum_f32(acc);
+      const float sc = l2 ? -sum : sum;
       if (lane == 0 && t0 + bb < n_cand) keys[t0 + bb] = make_key(sc, rows[bb]);   // the dense array is scratch now
     }
   }

@@ -45,6 +45,7 @@ class DeviceCorpus:
         self._ws: Dict[Tuple[int, int], "torch.Tensor"] = {}
         self._q_pinned = None
         self._q_dev = None
+        self.shadow = None            # bf16 copy of an fp32 matrix (enable_bf16_shadow): pre-selection for batches > 32 queries
         self._io: Dict[Tuple[int, int], tuple] = {}      # (batch, k) -> device + pinned result buffers of search()
         # The blocking search() stages queries and results through per-instance buffers (pinned query, device
         # query, cached result buffers, workspaces): one caller at a time.  The reference's ExactIndex.search is
@@ -96,6 +97,22 @@ class DeviceCorpus:
             nat.check(self._lib.dewi_convert_f32_to_bf16(nat.ptr(self.emb), nat.ptr(out), self.emb.numel(),
                                                          nat.stream_ptr()))
         return DeviceCorpus(out, self.dewi32, self.ent32, self.space, self.id_offset)
+
+    def enable_bf16_shadow(self) -> "DeviceCorpus":
+        """Keep a bf16 copy of this fp32 matrix next to it (+50 % memory).  Batches of more than 32 cosine queries then
+        run the 256-query matrix-core pass over the copy as a pre-selection — 256 queries per corpus pass over half the
+        bytes instead of 32 over all of them — and re-score the candidates from the fp32 rows with the row kernels'
+        arithmetic (``dewi_knn_rerank_f32_shadow``): results equal the one-query search bit for bit.  dim 256 / 512 / 768,
+        >= 64 K rows; any other shape simply takes the usual path."""
+        torch = _torch()
+        if self.is_bf16:
+            raise ValueError("the corpus is already bf16")
+        if self.shadow is None:
+            out = torch.empty(self.emb.shape, dtype=torch.bfloat16, device=self.device)
+            with torch.cuda.device(self.device):
+                nat.check(self._lib.dewi_convert_f32_to_bf16(nat.ptr(self.emb), nat.ptr(out), self.emb.numel(), nat.stream_ptr()))
+            self.shadow = out
+        return self
 
     # ------------------------------------------------------------------ properties
     @property
@@ -184,7 +201,12 @@ class DeviceCorpus:
         if candidates is None and similarity != "ip":
             raise ValueError("similarity transforms belong to the ANN re-rank rule: pass candidates=k as well")
         ws = self._workspace(b, max(c, 1))
-        if candidates is None:
+        if candidates is None and self.shadow is not None and b > 32:
+            rc = self._lib.dewi_knn_rerank_f32_shadow(
+                nat.ptr(self.emb), nat.ptr(self.shadow), self.n_rows, self.dim, nat.ptr(q_dev), b, nat.ptr(self.dewi32),
+                nat.ptr(self.ent32), k, float(eta), float(entropy_pref), nat.SPACE_CODES[self.space], nat.ptr(out_ids),
+                nat.ptr(out_scores), nat.ptr(ws), ws.numel(), nat.stream_ptr())
+        elif candidates is None:
             fn = self._lib.dewi_knn_rerank_bf16 if self.is_bf16 else self._lib.dewi_knn_rerank_f32
             rc = fn(nat.ptr(self.emb), self.n_rows, self.dim, nat.ptr(q_dev), b, nat.ptr(self.dewi32),
                     nat.ptr(self.ent32), k, float(eta), float(entropy_pref), nat.SPACE_CODES[self.space],

@@ -36,7 +36,7 @@ ABI_VERSION = 4
 #: every symbol include/dewi_hip.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = (
     "dewi_abi_version", "dewi_last_error", "dewi_device_info", "dewi_normalize_rows_f32",
-    "dewi_row_cosine_f32", "dewi_convert_f32_to_bf16", "dewi_payload_soa_f64", "dewi_knn_workspace_bytes", "dewi_knn_rerank_f32",
+    "dewi_row_cosine_f32", "dewi_convert_f32_to_bf16", "dewi_payload_soa_f64", "dewi_knn_workspace_bytes", "dewi_knn_rerank_f32", "dewi_knn_rerank_f32_shadow",
     "dewi_knn_rerank_bf16", "dewi_knn_rerank_candidates", "dewi_prepare_queries_bf16", "dewi_knn_scan", "dewi_knn_finish", "dewi_knn_candidates", "dewi_merge_workspace_bytes", "dewi_merge_rerank", "dewi_robust_fit_workspace_bytes",
     "dewi_robust_fit_f32", "dewi_robust_fit_begin", "dewi_robust_fit_hist_f32", "dewi_robust_fit_region",
     "dewi_robust_fit_pick", "dewi_robust_fit_finish", "dewi_score_f64", "dewi_score_f64_dev", "dewi_timing_enable", "dewi_timing_read", "dewi_tuning_set",
@@ -110,6 +110,8 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.dewi_score_f64.restype = i32
     lib.dewi_score_f64.argtypes = [vp, i32, i64, i64, c.POINTER(f64), c.POINTER(f64), c.POINTER(f64), f64, i32, vp,
                                    vp, vp]
+    lib.dewi_knn_rerank_f32_shadow.restype = i32
+    lib.dewi_knn_rerank_f32_shadow.argtypes = [vp, vp, i64, i32, vp, i32, vp, vp, i32, f64, f64, i32, vp, vp, vp, sz, vp]
     lib.dewi_score_f64_dev.restype = i32
     lib.dewi_score_f64_dev.argtypes = [vp, i32, i64, i64, vp, vp, c.POINTER(f64), f64, i32, vp, vp, vp]
     lib.dewi_timing_enable.restype = i32

@@ -141,6 +141,9 @@ class ExactIndex(BaseIndex):
         self._host_rows: Optional[np.ndarray] = None  # lazily materialised copy of the stored matrix
         self._loaded_rows: Optional[np.ndarray] = None  # rows read by load(): already in stored form
         self._device: Optional[str] = kwargs.get("device")
+        # additive: keep a bf16 shadow copy of the fp32 matrix (+50 % HBM) so that search_batch with more than 32 queries
+        # runs 256 queries per corpus pass as a pre-selection and re-scores exactly (DeviceCorpus.enable_bf16_shadow)
+        self._batch_shadow: bool = bool(kwargs.get("batch_shadow", False))
 
     # ---------------------------------------------------------------- ingest (A1)
     def add(self, doc_id: str, embedding: np.ndarray, payload: Payload) -> None:
@@ -294,6 +297,8 @@ class ExactIndex(BaseIndex):
                                                nat.ptr(dewi32), nat.ptr(ent32), n, nat.stream_ptr()))
             torch.cuda.current_stream().synchronize()
         self._corpus = DeviceCorpus(emb, dewi32, ent32, self.space)
+        if self._batch_shadow and self.space == "cosine":
+            self._corpus.enable_bf16_shadow()
         self._pending = []
         self._pending_rows = 0
         self._loaded_rows = None
@@ -327,7 +332,7 @@ class ExactIndex(BaseIndex):
                                                                          nat.stream_ptr()))
                     torch.cuda.current_stream().synchronize()
             corpus = head
-        self._corpus = corpus
+        self._corpus = corpus.enable_bf16_shadow() if self._batch_shadow and self.space == "cosine" else corpus
         self._pending = []
         self._pending_rows = 0
         self._loaded_rows = None

@@ -119,6 +119,19 @@ int dewi_knn_rerank_f32(const float* d_E, int64_t n_rows, int dim, const float* 
                         int space, int64_t* d_out_ids, float* d_out_scores, void* d_workspace,
                         size_t workspace_bytes, void* stream);
 
+/* The same search over an fp32 corpus that also has a bf16 SHADOW copy (d_E_bf16: the stored rows rounded with
+ * dewi_convert_f32_to_bf16; +50 % memory), for batches of more than 32 queries: the 256-query matrix-core pass runs over
+ * the shadow (half the bytes, 256 queries per corpus pass instead of 32) as a PRE-SELECTION — its scores are within a
+ * proven bound of the fp32 ones (bf16 rounding of unit vectors: 2^-8 plus accumulation), the candidate cut is widened by
+ * that bound — and the candidates are re-scored from the fp32 rows with the row kernels' arithmetic, so ids and scores
+ * equal dewi_knn_rerank_f32's one-query results bit for bit.  Cosine, dim 256 / 512 / 768, corpus >= 64 K rows;
+ * any other call (and d_E_bf16 == NULL) behaves exactly as dewi_knn_rerank_f32.  A query with more candidates inside
+ * the error band than the sort holds comes back refused (id -1) like any matrix-core batch.  (ABI 4.) */
+int dewi_knn_rerank_f32_shadow(const float* d_E, const uint16_t* d_E_bf16, int64_t n_rows, int dim, const float* d_Q,
+                               int n_queries, const float* d_dewi32, const float* d_ent32, int k, double eta,
+                               double entropy_pref, int space, int64_t* d_out_ids, float* d_out_scores,
+                               void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* A10 / F4  the same search with an explicit candidate count instead of min(2k, n_rows): n_candidates =
  * k reproduces the re-rank rule of the reference's HNSWIndex / FAISSIndex.search (backends.py:204-241,
  * 309-356: the library returns exactly k neighbours, which are then blended and sorted) on top of an

@@ -74,6 +74,9 @@ def one_search_case(i):
         kw = dict(gap=1e-6, score_tol=1e-5, prepared=True)
     else:
         E, Qo = c.emb.cpu().numpy(), Q
+        if space == "cosine" and dim in (256, 512, 768) and b > 32 and rs.rand() < 0.7:
+            c.enable_bf16_shadow()          # batches > 32: 256-query pass over the bf16 shadow + exact re-scoring
+            LAST.update(shadow=True)
     ids, sc = c.search(Q, k, eta, pref)
     assert ids.shape == (b, k)
     check = range(b) if b <= 16 else sorted(rs.choice(b, 16, replace=False).tolist())   # the oracle costs n*dim per query
@@ -90,7 +93,7 @@ def one_search_case(i):
         qd = torch.from_numpy(Q).cuda()
         lists = []
         for lo, hi in zip(cuts[:-1], cuts[1:]):
-            sh = eng.DeviceCorpus(c.emb[lo:hi], c.dewi32[lo:hi], c.ent32[lo:hi], space, id_offset=lo)
+            sh = eng.DeviceCorpus(c.emb[lo:hi], c.dewi32[lo:hi], c.ent32[lo:hi], space, id_offset=lo)   # (no shadow: shard records)
             lists.append(sh.candidates_device(qd, cc))
         case["cuts"] = cuts
         LAST.update(family="shards", cuts=cuts)
@@ -102,7 +105,8 @@ def one_search_case(i):
         both = (ok & m_ok).cpu().numpy()
         # per-row sums do not depend on the shard a row is in when the same kernel family serves both; a shard too
         # small for the matrix-core pass takes the row kernels (other summation order): compare through the oracle then
-        same_path = all((hi - lo) >= 64 * 1024 for lo, hi in zip(cuts[:-1], cuts[1:])) or b < (2 if bf16 else 5) or n < 64 * 1024
+        same_path = (all((hi - lo) >= 64 * 1024 for lo, hi in zip(cuts[:-1], cuts[1:])) or b < (2 if bf16 else 5) or n < 64 * 1024) \
+            and c.shadow is None
         # the bf16 row kernel takes 1536-byte rows in pairs: a row's sum depends on its place in the pair, so only
         # shards that start on even rows (what dewi.sharded.shard_bounds produces) are bit-equal to the whole there
         pairs_kept = not (bf16 and dim == 768) or all(lo % 2 == 0 for lo in cuts[:-1])
