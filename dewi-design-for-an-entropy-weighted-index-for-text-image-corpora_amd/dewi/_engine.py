@@ -107,7 +107,15 @@ class DeviceCorpus:
         torch = _torch()
         if self.is_bf16:
             raise ValueError("the corpus is already bf16")
+        if self.space != "cosine":
+            raise ValueError("the bf16 shadow serves cosine corpora (stored rows of unit norm)")
         if self.shadow is None:
+            # the error bound of the pre-selection (2^-8 of ||e|| ||q|| + accumulation) is proven for rows of norm <= 1.0001:
+            # the stored form of a cosine corpus.  Checked once (NaN rows — zero embeddings — are fine: they rank first).
+            worst = float(torch.nan_to_num(torch.linalg.vector_norm(self.emb, dim=1), nan=0.0).max()) if self.n_rows else 0.0
+            if worst > 1.0001:
+                raise ValueError(f"rows are not normalised (largest norm {worst:.6f}): the bf16 shadow's error bound "
+                                 f"does not hold for this matrix")
             out = torch.empty(self.emb.shape, dtype=torch.bfloat16, device=self.device)
             with torch.cuda.device(self.device):
                 nat.check(self._lib.dewi_convert_f32_to_bf16(nat.ptr(self.emb), nat.ptr(out), self.emb.numel(), nat.stream_ptr()))

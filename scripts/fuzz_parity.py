@@ -42,9 +42,9 @@ LAST = {}
 
 def one_search_case(i):
     if args.big:
-        dim = int(rs.choice([128, 256, 384, 512, 640, 768, 1024, 1536]))
+        dim = int(rs.choice([128, 256, 256, 384, 512, 512, 640, 768, 768, 768, 1024, 1536]))
         n = int(rs.randint(65_536, 160_000))
-        bf16 = bool(rs.rand() < 0.6)
+        bf16 = bool(rs.rand() < 0.45)
         space = "l2" if rs.rand() < 0.2 else "cosine"
         b = int(rs.choice([2, 5, 8, 31, 32, 33, 64, 65, 100, 256, 257, 300]))
         k = int(rs.choice([1, 5, 10, 50, 100, 128, 129, 300, 1000]))
@@ -77,6 +77,7 @@ def one_search_case(i):
         if space == "cosine" and dim in (256, 512, 768) and b > 32 and rs.rand() < 0.7:
             c.enable_bf16_shadow()          # batches > 32: 256-query pass over the bf16 shadow + exact re-scoring
             LAST.update(shadow=True)
+            done["shadow"] = done.get("shadow", 0) + 1
     ids, sc = c.search(Q, k, eta, pref)
     assert ids.shape == (b, k)
     check = range(b) if b <= 16 else sorted(rs.choice(b, 16, replace=False).tolist())   # the oracle costs n*dim per query

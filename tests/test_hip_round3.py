@@ -476,3 +476,14 @@ def test_fp32_corpus_with_bf16_shadow_equals_the_one_query_search(dim, n, b, k):
     assert np.mean(ids_p == ids) > 0.98 and np.allclose(np.sort(sc_p, axis=1), np.sort(sc, axis=1), rtol=0, atol=2e-6)
     ids2, sc2 = c.search(Q, k, 0.3, 0.1)                             # deterministic
     assert np.array_equal(ids2, ids) and np.array_equal(sc2, sc)
+
+
+def test_bf16_shadow_refuses_rows_that_are_not_normalised():
+    import torch
+    eng = _engine()
+    emb = torch.randn((1000, 256), device="cuda") * 3.0
+    z = torch.zeros(1000, device="cuda")
+    with pytest.raises(ValueError, match="not normalised"):
+        eng.DeviceCorpus(emb, z, z, "cosine").enable_bf16_shadow()
+    with pytest.raises(ValueError, match="cosine"):
+        eng.DeviceCorpus(emb, z, z, "l2").enable_bf16_shadow()
