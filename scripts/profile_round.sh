@@ -46,6 +46,7 @@ probe_pmc() {     # dir suffix, counters, probe args...
 trace c2 --steps 300 --warmup 30
 trace c3 --config c3 --steps 40 --warmup 5
 trace c5 --config c5 --steps 20 --warmup 3
+trace c2b256 --batch 256 --steps 60 --warmup 10
 pmc FETCH_SIZE_c2 FETCH_SIZE --steps 40 --warmup 5
 pmc WRITE_SIZE_c2 WRITE_SIZE --steps 40 --warmup 5
 pmc FETCH_SIZE_c3 FETCH_SIZE --config c3 --steps 10 --warmup 2
