@@ -302,8 +302,10 @@ int batch_select(const BatchPlan& P, void* d_ws, size_t ws_bytes, int n_queries,
   // counts: query-major for the 256-query pass (coalesced in the select kernel), segment-major for the depth-split pass
   // (LDS staging of a query's survivors: 8192 records; 12288 when the scores only pre-select for the exact re-scoring of
   // an fp32 corpus — its thresholds sit two error bounds lower, ~10 K survivors per query at k = 100)
-  const dewi::SegmentLayout seg{n_seg, seg_cap, 1, static_cast<int64_t>(per) * seg_cap, big ? 1 : per,
-                                (big && d_Q_shadow != nullptr) ? 12288 : 8192, big ? n_seg : 1};
+  // DEWI_STAGE_KEYS (tests only): shrink the staging so that the over-capacity routes of the select kernel run on small inputs
+  static const int stage_override = [] { const char* e = getenv("DEWI_STAGE_KEYS"); return e ? atoi(e) : 0; }();
+  const int stage_keys = stage_override > 0 ? stage_override : ((big && d_Q_shadow != nullptr) ? 12288 : 8192);
+  const dewi::SegmentLayout seg{n_seg, seg_cap, 1, static_cast<int64_t>(per) * seg_cap, big ? 1 : per, stage_keys, big ? n_seg : 1};
   // exact-refine modes: l2 on the depth-split pass over an fp32 corpus (queries and norms as the scan left them in the
   // workspace), or the 256-query pass over the bf16 SHADOW of an fp32 corpus (d_Q_shadow = the caller's raw queries)
   const bool refine_l2 = !big && space == DEWI_SPACE_L2 && elem_type == 0;
@@ -458,7 +460,7 @@ int dewi_knn_rerank_f32_shadow(const float* d_E, const uint16_t* d_E_bf16, int64
   // the shadow pre-selects only where the 256-query pass runs and the one-query search of the same corpus takes the
   // row-per-wave kernel whose arithmetic the refinement repeats (dim 256 / 512 / 768); everything else is the plain search
   const bool use = d_E_bf16 != nullptr && g_tuning.mfma != 0 && space == DEWI_SPACE_COSINE && n_queries > 32 && k > 0 &&
-                   k <= n_rows && (dim == 256 || dim == 512 || dim == 768) && c64 <= dewi::kMaxSortCandidates &&
+                   k <= n_rows && (dim == 256 || dim == 512 || dim == 768) && c64 <= 512 &&
                    dewi::mfma_path_supported(n_rows, dim, n_queries, static_cast<int>(c64), space);
   if (!use)
     return knn_rerank_impl(d_E, 0, n_rows, dim, d_Q, n_queries, d_dewi32, d_ent32, k, eta, entropy_pref, space, d_out_ids,
@@ -468,7 +470,7 @@ int dewi_knn_rerank_f32_shadow(const float* d_E, const uint16_t* d_E_bf16, int64
   BatchPlan P{};
   P.path = BatchPath::Big;
   P.c_local = c;
-  P.big = dewi::plan_mfma(n_rows, dim, n_queries, c, dev.cus);
+  P.big = dewi::plan_mfma(n_rows, dim, n_queries, c, dev.cus, true);
   P.total = P.big.total;
   if (!d_workspace || workspace_bytes < P.total) return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, P.total);
   // scores from bf16(e), bf16(q) are within shadow_margin of the fp32 row kernels': the sample's c-th best minus the bound is

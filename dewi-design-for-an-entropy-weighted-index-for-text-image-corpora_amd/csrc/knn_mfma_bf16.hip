@@ -663,13 +663,17 @@ bool mfma_path_supported(int64_t n_rows, int dim, int n_queries, int n_candidate
          n_rows / (kTileRows * kSampleStride) * kTileRows >= 4 * static_cast<int64_t>(n_candidates);
 }
 
-MfmaLayout plan_mfma(int64_t n_rows, int dim, int n_queries, int n_candidates, int compute_units) {
+MfmaLayout plan_mfma(int64_t n_rows, int dim, int n_queries, int n_candidates, int compute_units, bool preselect) {
   MfmaLayout m{};
   auto up = [](size_t v) { return (v + 255) / 256 * 256; };
   m.groups = (n_queries + kQueriesPerPass - 1) / kQueriesPerPass;
   m.q_pad = m.groups * kQueriesPerPass;
   m.n_tiles = (n_rows + kTileRows - 1) / kTileRows;
-  m.n_sample_tiles = (m.n_tiles + kSampleStride - 1) / kSampleStride;
+  // Pre-selection for an exact re-scoring lowers every threshold by two error bounds (~0.008 in cosine at dim 768): at c = 200
+  // that alone adds ~5 K survivors per query behind a 1/32 sample.  A finer sample puts the threshold higher up the tail,
+  // where the same band holds fewer rows: ~6 K survivors at c = 200 with 1/16 (1 M x 768 gaussian rows), ~7.5 K at c = 500 with 1/8.
+  m.tile_stride = !preselect || n_candidates <= 64 ? kSampleStride : (n_candidates <= 256 ? kSampleStride / 2 : kSampleStride / 4);
+  m.n_sample_tiles = (m.n_tiles + m.tile_stride - 1) / m.tile_stride;
   // group maxima per query: sample workgroups x 2 lane halves x 16 accumulator registers
   const int64_t sample_blocks = m.n_sample_tiles < compute_units ? m.n_sample_tiles : compute_units;
   m.sample_stride = sample_blocks * 32;
@@ -678,7 +682,7 @@ MfmaLayout plan_mfma(int64_t n_rows, int dim, int n_queries, int n_candidates, i
   // 4x head-room, at least 32 records.
   m.n_blocks = m.n_tiles < compute_units ? static_cast<int>(m.n_tiles) : compute_units;
   m.n_seg = kSegPerBlock * m.n_blocks;
-  int64_t cap = (4ll * kSampleStride * n_candidates + m.n_seg - 1) / m.n_seg;
+  int64_t cap = (4ll * kSampleStride * n_candidates + m.n_seg - 1) / m.n_seg;   // (sized for the 1/32 sample: head-room for the band)
   m.seg_cap = static_cast<int>(cap < 32 ? 32 : cap);
   size_t off = 0;
   m.qb_off = off;      off += up(static_cast<size_t>(m.q_pad) * dim * 2);
@@ -745,7 +749,7 @@ static hipError_t run_mfma_dim(const MfmaLayout& m, const uint16_t* E, int64_t n
     const int sample_blocks = m.n_sample_tiles < compute_units ? static_cast<int>(m.n_sample_tiles) : compute_units;
     const ScanKernel k_sample = scan_kernel<KS, true>(), k_filter = scan_kernel<KS, false>();
     hipLaunchKernelGGL(k_sample, dim3(sample_blocks), dim3(kMfmaThreads), lds_bytes, stream, E, n_rows,
-                       qg, m.n_sample_tiles, static_cast<int64_t>(kSampleStride), static_cast<const float*>(nullptr),
+                       qg, m.n_sample_tiles, static_cast<int64_t>(m.tile_stride), static_cast<const float*>(nullptr),
                        reinterpret_cast<uint64_t*>(dense), m.sample_stride, static_cast<uint32_t*>(nullptr), n_active, 0.f);
     // 2. per-query threshold (real queries only: a padding query's sample scores are all equal, which is the
     //    worst case of the histogram select, and its threshold is not used)

@@ -100,7 +100,8 @@ struct MfmaLayout {
   int groups;              // passes of up to 256 queries
   int q_pad;               // groups * 256
   int64_t n_tiles;         // 32-row tiles
-  int64_t n_sample_tiles;  // every 32nd tile
+  int64_t n_sample_tiles;  // every tile_stride-th tile
+  int tile_stride;         // 32; 16 / 8 when the scores only pre-select (bf16 shadow of an fp32 corpus) and c is large
   int64_t sample_stride;   // group maxima per query the sample pass emits (sample workgroups * 32)
   int n_blocks;            // workgroups of the filter pass
   int n_seg;               // candidate half-segments per query (2 per workgroup)
@@ -111,7 +112,9 @@ struct MfmaLayout {
 hipError_t launch_prepare_queries_bf16(const float* d_Q, uint16_t* d_out, int n_queries, int n_rows_out, int dim, int space,
                                        float* d_qn2, hipStream_t stream);
 bool mfma_path_supported(int64_t n_rows, int dim, int n_queries, int n_candidates, int space);
-MfmaLayout plan_mfma(int64_t n_rows, int dim, int n_queries, int n_candidates, int compute_units);
+// preselect: the pass runs over the bf16 shadow of an fp32 corpus (thresholds two error bounds lower: a finer sample keeps
+// the survivors of a query inside what the select kernel stages)
+MfmaLayout plan_mfma(int64_t n_rows, int dim, int n_queries, int n_candidates, int compute_units, bool preselect = false);
 // Fills cand keys [groups][n_seg][256][seg_cap] and counts [groups][256][n_seg] in the workspace.
 // thr_bias: subtracted from every query's threshold in the filter pass (0: exact scores; 2 * shadow_margin(dim): the
 // scores pre-select for an exact re-scoring of an fp32 corpus)

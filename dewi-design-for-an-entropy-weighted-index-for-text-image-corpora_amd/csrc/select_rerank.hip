@@ -186,40 +186,91 @@ __device__ int top_candidates_lds(const uint64_t* keys, int n, int n_candidates,
 // Returns the number of valid keys in sh.sel, or -2 when more candidates qualify than sh.sel2 holds (the query is
 // refused and the caller re-runs it on the row kernels).  The dense array doubles as scratch once the candidates are
 // compacted.
+// Part 1 (two sources): find the cut and compact the candidates into sh.sel2; returns their number.
+__device__ __forceinline__ float refine_bound(const RefineParams& rf, float q2, float a) {
+  const float d = a < 0.f ? -a : 0.f;              // M(a); NaN scores (NaN rows rank first) get an infinite bound
+  return a == a ? (rf.space == DEWI_SPACE_L2 ? rf.margin * (3.f * q2 + 2.f * d) * 1.01f : rf.margin) : __builtin_inff();
+}
+__device__ __forceinline__ float refine_low(const RefineParams& rf, float q2, uint64_t thr) {
+  if (thr == 1ull) return -__builtin_inff();       // fewer than c keys: every key is a candidate
+  const float a_c = key_score(thr);
+  const float low = a_c - refine_bound(rf, q2, a_c);
+  return low == low ? low : -__builtin_inff();
+}
+// wave-aggregated append of `key` (if pass) to sh.sel2: one LDS atomic per wave and call
+__device__ __forceinline__ void refine_append(SelectShared& sh, bool pass, uint64_t key, int lane) {
+  const unsigned long long m = __ballot(pass);
+  if (m != 0ull) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&sh.count, static_cast<uint32_t>(__popcll(m)));
+    base = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(base)));
+    const uint32_t pos = base + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
+    if (pass && pos < static_cast<uint32_t>(kMaxSortCandidates)) sh.sel2[pos] = key;
+  }
+}
+
+__device__ __forceinline__ int refine_rescore(uint64_t* keys, int n_candidates, SelectShared& sh, const RefineParams& rf, int q);
+
+// survivors staged in LDS (`keys`, n of them)
 __device__ __forceinline__ int refine_top_candidates(uint64_t* keys, int n, int n_candidates, SelectShared& sh,
                                                      WideRadixShared& ws, const RefineParams& rf, int q) {
   const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
-  const int lane = tid & 63, wave = tid >> 6, n_waves = nt >> 6;
+  const int lane = tid & 63;
   const uint64_t thr = block_kth_largest_lds(keys, n, static_cast<uint32_t>(n_candidates), ws);
-  const bool l2 = rf.space == DEWI_SPACE_L2;
-  const float q2 = l2 ? rf.qn2[q] : 0.f;
-  auto bound = [&](float a) {                      // M(a); NaN scores (NaN rows rank first) get an infinite bound
-    const float d = a < 0.f ? -a : 0.f;
-    return a == a ? (l2 ? rf.margin * (3.f * q2 + 2.f * d) * 1.01f : rf.margin) : __builtin_inff();
-  };
-  float low = -__builtin_inff();                   // fewer than c keys: every key is a candidate
-  if (thr != 1ull) {
-    const float a_c = key_score(thr);
-    low = a_c - bound(a_c);
-    if (!(low == low)) low = -__builtin_inff();
-  }
+  const float q2 = rf.space == DEWI_SPACE_L2 ? rf.qn2[q] : 0.f;
+  const float low = refine_low(rf, q2, thr);
   if (tid == 0) sh.count = 0;
   __syncthreads();
-  for (int i0 = 0; i0 < n; i0 += nt) {             // compaction: one LDS atomic per wave and round
+  for (int i0 = 0; i0 < n; i0 += nt) {
     const int i = i0 + tid;
     const uint64_t key = i < n ? keys[i] : kKeyEmpty;
     const float a = key_score(key);
-    const bool pass = key != kKeyEmpty && !(a + bound(a) < low);
-    const unsigned long long m = __ballot(pass);
-    if (m != 0ull) {
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(&sh.count, static_cast<uint32_t>(__popcll(m)));
-      base = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(base)));
-      const uint32_t pos = base + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
-      if (pass && pos < static_cast<uint32_t>(kMaxSortCandidates)) sh.sel2[pos] = key;
+    refine_append(sh, key != kKeyEmpty && !(a + refine_bound(rf, q2, a) < low), key, lane);
+  }
+  __syncthreads();
+  return refine_rescore(keys, n_candidates, sh, rf, q);
+}
+
+// more survivors than the staging holds (dense data, large c): the same two steps over the segments in global memory —
+// the 8-bit radix select re-reads them once per pass (slower, L2-resident), nothing is refused.  `scratch`: >= 2048 keys.
+__device__ __forceinline__ int refine_from_segments(const SegmentKeys& kv, uint64_t* scratch, int n_candidates, SelectShared& sh,
+                                                    const RefineParams& rf, int q) {
+  const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
+  const int lane = tid & 63;
+  const uint64_t thr = block_kth_largest(kv, static_cast<uint32_t>(n_candidates), sh);
+  const float q2 = rf.space == DEWI_SPACE_L2 ? rf.qn2[q] : 0.f;
+  const float low = refine_low(rf, q2, thr);
+  if (tid == 0) sh.count = 0;
+  __syncthreads();
+  // every thread walks the same number of (segment, slot) steps so that the ballots inside refine_append are wave-wide
+  constexpr int kGroup = 4;
+  const int sub = tid % kGroup;
+  for (int seg0 = 0; seg0 < kv.n_seg; seg0 += nt / kGroup) {
+    const int seg = seg0 + tid / kGroup;
+    uint32_t cnt = seg < kv.n_seg ? kv.count[seg * kv.count_stride] : 0u;
+    cnt = cnt < static_cast<uint32_t>(kv.cap) ? cnt : static_cast<uint32_t>(kv.cap);
+    const uint32_t steps = static_cast<uint32_t>(kv.cap + kGroup - 1) / kGroup;
+    for (uint32_t st = 0; st < steps; ++st) {
+      const uint32_t j = st * kGroup + sub;
+      uint64_t key = kKeyEmpty;
+      if (j < cnt) {
+        const uint64_t v = kv.p[seg * kv.seg_stride + j];
+        key = kv.raw ? make_key(__uint_as_float(static_cast<uint32_t>(v)), static_cast<uint32_t>(v >> 32)) : v;
+      }
+      if (__builtin_amdgcn_ballot_w64(j < cnt) == 0ull) break;          // this wave's segments are exhausted
+      const float a = key_score(key);
+      refine_append(sh, key != kKeyEmpty && !(a + refine_bound(rf, q2, a) < low), key, lane);
     }
   }
   __syncthreads();
+  return refine_rescore(scratch, n_candidates, sh, rf, q);
+}
+
+// Part 2: sh.count candidates in sh.sel2 -> exact scores -> the best n_candidates, sorted, in sh.sel.
+__device__ __forceinline__ int refine_rescore(uint64_t* keys, int n_candidates, SelectShared& sh, const RefineParams& rf, int q) {
+  const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
+  const int lane = tid & 63, wave = tid >> 6, n_waves = nt >> 6;
+  const bool l2 = rf.space == DEWI_SPACE_L2;
   const int n_cand = static_cast<int>(sh.count);
   if (n_cand > kMaxSortCandidates) return -2;
   // exact scores, one wave per candidate, kBatch candidates per wave and round with all their loads in flight together
@@ -552,8 +603,11 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(
           n_sel = top_candidates_lds(dyn_keys, static_cast<int>(total), n_candidates, sh, ws);
         }
       } else if (refine.E != nullptr) {
-        refuse();                 // the refinement works on the staged records only (more than 8192 survivors: adversarial)
-        return;
+        n_sel = refine_from_segments(kv, dyn_keys, n_candidates, sh, refine, q);   // more survivors than the staging holds
+        if (n_sel == -2) {
+          refuse();
+          return;
+        }
       } else {
         n_sel = exact_top_candidates(kv, n_candidates, sh);   // more survivors than LDS holds
       }

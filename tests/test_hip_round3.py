@@ -487,3 +487,38 @@ def test_bf16_shadow_refuses_rows_that_are_not_normalised():
         eng.DeviceCorpus(emb, z, z, "cosine").enable_bf16_shadow()
     with pytest.raises(ValueError, match="cosine"):
         eng.DeviceCorpus(emb, z, z, "l2").enable_bf16_shadow()
+
+
+def test_refine_routes_when_the_survivors_do_not_fit_the_staging():
+    """The exact-refine select stages a query's survivors in LDS; when there are more than it holds it takes the same
+    steps over the segments in global memory instead of refusing.  A child process with the staging shrunk to 512 keys
+    (DEWI_STAGE_KEYS, a test switch) runs the bf16-shadow batch and the l2 batch that way: both must still equal the
+    one-query searches bit for bit."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parent.parent
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, r'%s'); sys.path.insert(0, r'%s')
+import dewi_oracle as orc
+from dewi import _engine as eng
+n, d, b, k = 70_000, 256, 40, 20
+raw = orc.synth_corpus(n, d, seed=5); cols = orc.synth_payload_columns(n, seed=5); Q = orc.synth_queries(b, d, seed=6)
+plain = eng.DeviceCorpus.from_host(raw, cols['dewi'], cols['ht_mean'], cols['hi_mean'])
+sh = eng.DeviceCorpus(plain.emb, plain.dewi32, plain.ent32, 'cosine').enable_bf16_shadow()
+ids, sc = sh.search(Q, k, 0.3, 0.1)
+for j in range(b):
+    i1, s1 = plain.search(Q[j], k, 0.3, 0.1)
+    assert np.array_equal(ids[j], i1[0]) and np.array_equal(sc[j], s1[0]), ('shadow', j)
+l2 = eng.DeviceCorpus.from_host(raw * 2.5, cols['dewi'], cols['ht_mean'], cols['hi_mean'], space='l2')
+ids, sc = l2.search(Q, k, 0.3, 0.1)
+for j in range(b):
+    i1, s1 = l2.search(Q[j], k, 0.3, 0.1)
+    assert np.array_equal(ids[j], i1[0]) and np.array_equal(sc[j], s1[0]), ('l2', j)
+print('OK')
+""" % (repo / "dewi-design-for-an-entropy-weighted-index-for-text-image-corpora_amd", repo / "oracle")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, DEWI_STAGE_KEYS="512"))
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stderr[-3000:]
