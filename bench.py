@@ -70,6 +70,9 @@ def parse_args():
     ap.add_argument("--eta", type=float, default=0.3)
     ap.add_argument("--batch", type=int, default=None, help="queries per step")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--shadow", type=int, default=-1,
+                    help="bf16 shadow copy of the fp32 corpus for query batches (pre-selection + exact re-scoring): 1 on, 0 off, "
+                         "-1 = on for --batch > 32")
     ap.add_argument("--emulate-shards", type=int, default=8, help="--config c4: resident shards on the one GPU")
     ap.add_argument("--cpu-queries", type=int, default=512,
                     help="queries timed on the CPU oracle: ~10 s of CPU work at C2, cut off after 30 s (0 = skip; at least 50 are run)")
@@ -273,7 +276,7 @@ def run_c2(args, torch, dist, eng, nat, rank, world, device):
     corpus = eng.DeviceCorpus(emb_raw, dewi32, ent32, "cosine", id_offset=lo)
     n_q = args.warmup + args.steps
     B = args.batch
-    shadowed = B > 32 and world == 1 and args.dim in (256, 512, 768)
+    shadowed = (B > 32 if args.shadow < 0 else (args.shadow == 1 and B >= 2)) and world == 1 and args.dim in (256, 512, 768)
     if shadowed:
         # batches of more than 32 queries over the fp32 corpus: 256-query pass over a bf16 shadow copy as a pre-selection,
         # candidates re-scored from the fp32 rows (dewi_knn_rerank_f32_shadow): fp32-exact results, +50 % memory
@@ -435,8 +438,8 @@ def run_c2(args, torch, dist, eng, nat, rank, world, device):
     achieved = algo_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     # --batch >= 5 over the fp32 corpus: the depth-split matrix-core pass is the dominant kernel (one per 32 queries);
     # --batch > 32: the 256-query pass over the bf16 shadow (one per 256 queries)
-    kernel = ("scan_rows_f32" if B < 5 else f"mfma_scan_f32<false,{args.dim // 256},false,false>" if not shadowed
-              else f"mfma_scan_bf16_s16<{args.dim // 16},false>")
+    kernel = ("scan_rows_f32" if (B < 5 and not shadowed) else f"mfma_scan_f32<false,{args.dim // 256},false,false>" if not shadowed
+              else f"mfma_scan_bf16_s16<{args.dim // 16},false>" if B > 32 else f"mfma_scan_f32<true,{args.dim // 256},false,false>")
     traffic, traffic_note = recorded_traffic(f"{n_local}x{args.dim}x{elem}xB{B}", kernel)
 
     result = {

@@ -309,7 +309,7 @@ int batch_select(const BatchPlan& P, void* d_ws, size_t ws_bytes, int n_queries,
   // exact-refine modes: l2 on the depth-split pass over an fp32 corpus (queries and norms as the scan left them in the
   // workspace), or the 256-query pass over the bf16 SHADOW of an fp32 corpus (d_Q_shadow = the caller's raw queries)
   const bool refine_l2 = !big && space == DEWI_SPACE_L2 && elem_type == 0;
-  const bool refine_shadow = big && d_Q_shadow != nullptr;
+  const bool refine_shadow = d_Q_shadow != nullptr;
   const bool refine = refine_l2 || refine_shadow;
   if (refine && !d_E) return fail(DEWI_ERR_INVALID_ARG, "l2 over an fp32 corpus: the finish step needs the corpus pointer");
   for (int g = 0; g < groups && e == hipSuccess; ++g) {
@@ -431,8 +431,10 @@ size_t dewi_knn_workspace_bytes(int64_t n_rows, int dim, int n_queries, int n_ca
   }
   for (int et = 0; et < 2; ++et) {
     if (dewi::mfma_f32_path_supported(et, n_rows, dim, n_queries, n_candidates, DEWI_SPACE_COSINE)) {
-      const size_t m = dewi::plan_mfma_f32(et, n_rows, dim, n_queries, n_candidates, dev.cus).total;
-      if (m > a) a = m;
+      for (int pre = 0; pre < 2; ++pre) {     // (pre = 1: the pass pre-selects over a bf16 shadow, finer sample)
+        const size_t m = dewi::plan_mfma_f32(et, n_rows, dim, n_queries, n_candidates, dev.cus, pre != 0).total;
+        if (m > a) a = m;
+      }
     }
   }
   return a;  // valid for either element type and every path (small-batch scans, bf16 / fp32 matrix-core)
@@ -457,26 +459,38 @@ int dewi_knn_rerank_f32_shadow(const float* d_E, const uint16_t* d_E_bf16, int64
   rc = ensure_device(dev);
   if (rc) return rc;
   const int64_t c64 = (2ll * k < n_rows) ? 2ll * k : n_rows;
-  // the shadow pre-selects only where the 256-query pass runs and the one-query search of the same corpus takes the
+  // the shadow pre-selects only where a matrix-core pass runs over it and the one-query search of the same corpus takes the
   // row-per-wave kernel whose arithmetic the refinement repeats (dim 256 / 512 / 768); everything else is the plain search
-  const bool use = d_E_bf16 != nullptr && g_tuning.mfma != 0 && space == DEWI_SPACE_COSINE && n_queries > 32 && k > 0 &&
-                   k <= n_rows && (dim == 256 || dim == 512 || dim == 768) && c64 <= 512 &&
-                   dewi::mfma_path_supported(n_rows, dim, n_queries, static_cast<int>(c64), space);
-  if (!use)
+  const bool usable = d_E_bf16 != nullptr && g_tuning.mfma != 0 && space == DEWI_SPACE_COSINE && k > 0 && k <= n_rows &&
+                      (dim == 256 || dim == 512 || dim == 768);
+  const bool use_big = usable && n_queries > 32 && c64 <= 512 &&
+                       dewi::mfma_path_supported(n_rows, dim, n_queries, static_cast<int>(c64), space);
+  const bool use_depth = usable && !use_big && c64 <= 256 &&
+                         dewi::mfma_f32_path_supported(1, n_rows, dim, n_queries, static_cast<int>(c64), space);
+  if (!use_big && !use_depth)
     return knn_rerank_impl(d_E, 0, n_rows, dim, d_Q, n_queries, d_dewi32, d_ent32, k, eta, entropy_pref, space, d_out_ids,
                            d_out_scores, d_workspace, workspace_bytes, stream_);
   if (!d_dewi32 || !d_ent32 || !d_out_ids || !d_out_scores) return fail(DEWI_ERR_INVALID_ARG, "null payload or output pointer");
   const int c = static_cast<int>(c64);
   BatchPlan P{};
-  P.path = BatchPath::Big;
   P.c_local = c;
-  P.big = dewi::plan_mfma(n_rows, dim, n_queries, c, dev.cus, true);
-  P.total = P.big.total;
+  if (use_big) {
+    P.path = BatchPath::Big;
+    P.big = dewi::plan_mfma(n_rows, dim, n_queries, c, dev.cus, true);
+    P.total = P.big.total;
+  } else {
+    P.path = BatchPath::Depth;     // 2..32 queries (and larger batches the 256-query pass does not take): passes of 32 over the shadow
+    P.depth = dewi::plan_mfma_f32(1, n_rows, dim, n_queries, c, dev.cus, true);
+    P.total = P.depth.total;
+  }
   if (!d_workspace || workspace_bytes < P.total) return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, P.total);
   // scores from bf16(e), bf16(q) are within shadow_margin of the fp32 row kernels': the sample's c-th best minus the bound is
   // a lower bound of the exact c-th best, and a row may score that much lower here than exactly -> thresholds - 2 bounds
-  hipError_t e = dewi::launch_mfma_bf16(P.big, d_E_bf16, n_rows, dim, d_Q, n_queries, c, space, static_cast<char*>(d_workspace),
-                                        dev.cus, stream, 2.f * dewi::shadow_margin(dim));
+  const float bias = 2.f * dewi::shadow_margin(dim);
+  hipError_t e = use_big ? dewi::launch_mfma_bf16(P.big, d_E_bf16, n_rows, dim, d_Q, n_queries, c, space,
+                                                  static_cast<char*>(d_workspace), dev.cus, stream, bias)
+                         : dewi::launch_mfma_f32(P.depth, 1, d_E_bf16, n_rows, dim, d_Q, n_queries, c, space,
+                                                 static_cast<char*>(d_workspace), stream, bias);
   if (e != hipSuccess) return hip_fail(e, "mfma scan launch (bf16 shadow)");
   return batch_select(P, d_workspace, workspace_bytes, n_queries, c, k, make_rerank(eta, entropy_pref, DEWI_SIM_RAW, space), d_dewi32,
                       d_ent32, 0, d_out_ids, d_out_scores, nullptr, stream, d_E, 0, dim, space, d_Q);

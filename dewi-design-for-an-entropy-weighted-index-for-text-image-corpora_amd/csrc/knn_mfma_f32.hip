@@ -155,7 +155,10 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
                                                                 int64_t tile_stride, const float* __restrict__ thr,
                                                                 uint64_t* __restrict__ out, int64_t out_stride,
                                                                 uint32_t* __restrict__ cnt, int n_active,
-                                                                const float* __restrict__ qn2, float l2_margin) {
+                                                                const float* __restrict__ qn2, float aux) {
+  // aux: l2 — the error bound per unit of ||e||^2 + ||q||^2 (exact-refine mode, 0 = unrefined); cosine — a bias subtracted
+  // from every threshold (0, or two error bounds when the pass pre-selects over the bf16 shadow of an fp32 corpus)
+  const float l2_margin = L2 ? aux : 0.f;
 #if defined(__HIP_DEVICE_COMPILE__)
   using G = DepthGeo<BF16>;
   constexpr int DIM = CH * kF32ChunkCols;
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
       for (int m = 0; m < G::kReads; ++m) qf[ch][m] = raw[m];
     }
   }
-  const float thr_l = SAMPLE ? -__builtin_inff() : (r < n_active ? thr[r] : __builtin_inff());
+  const float thr_l = SAMPLE ? -__builtin_inff() : (r < n_active ? thr[r] - (L2 ? 0.f : aux) : __builtin_inff());
   const float qn2_l = L2 ? qn2[r] : 0.f;
   // pin the waits for these loads here, before any DMA is in flight (a compiler-inserted vmcnt(0) inside the
   // chunk loop would drain the ring on every iteration)
@@ -596,7 +599,8 @@ bool mfma_f32_path_supported(int elem_type, int64_t n_rows, int dim, int n_queri
          ch <= 6 && ch != 5 && n_rows >= 64 * 1024 && n_candidates <= 256;
 }
 
-MfmaF32Layout plan_mfma_f32(int elem_type, int64_t n_rows, int dim, int n_queries, int n_candidates, int compute_units) {
+MfmaF32Layout plan_mfma_f32(int elem_type, int64_t n_rows, int dim, int n_queries, int n_candidates, int compute_units,
+                            bool preselect) {
   MfmaF32Layout m{};
   auto up = [](size_t v) { return (v + 255) / 256 * 256; };
   m.groups = (n_queries + kF32Queries - 1) / kF32Queries;
@@ -604,7 +608,8 @@ MfmaF32Layout plan_mfma_f32(int elem_type, int64_t n_rows, int dim, int n_querie
   m.n_tiles = (n_rows + kF32TileRows - 1) / kF32TileRows;
   // Sample every `stride`-th tile: expected survivors per query ~ stride * c; keep that near 4 K (the select kernel
   // stages up to 8 K records in LDS) and the sample at no less than one tile per workgroup of the chip.
-  int64_t stride = 4096 / (n_candidates > 0 ? n_candidates : 1);
+  // (preselect: thresholds two error bounds lower — a finer sample keeps the survivors of a query inside the staging)
+  int64_t stride = (preselect ? 2048 : 4096) / (n_candidates > 0 ? n_candidates : 1);
   if (stride > 128) stride = 128;
   if (stride < 8) stride = 8;
   while (stride > 8 && (m.n_tiles + stride - 1) / stride < compute_units) stride /= 2;
@@ -630,10 +635,10 @@ MfmaF32Layout plan_mfma_f32(int elem_type, int64_t n_rows, int dim, int n_querie
 
 template <bool BF16, int CH, bool L2>
 static hipError_t run_mfma_f32_dim(const MfmaF32Layout& m, const void* E, int64_t n_rows, int n_queries, int n_candidates,
-                                   char* ws, hipStream_t stream) {
+                                   char* ws, hipStream_t stream, float thr_bias) {
   // l2 over an fp32 corpus runs in exact-refine mode (see stage2_finish and select_rerank.hip): error bound per unit of
   // ||e||^2 + ||q||^2.  bf16 corpora (opt-in, approximate) and cosine: no margin.
-  const float l2_margin = (L2 && !BF16) ? depth_l2_margin(CH * kF32ChunkCols) : 0.f;
+  const float l2_margin = L2 ? (BF16 ? 0.f : depth_l2_margin(CH * kF32ChunkCols)) : thr_bias;   // the kernel's `aux`
   constexpr int DIM = CH * kF32ChunkCols;
   constexpr int kLds = depth_lds_bytes<BF16>();
   static PerDeviceOnce attr_once;   // one per instantiation
@@ -676,7 +681,7 @@ static hipError_t run_mfma_f32_dim(const MfmaF32Layout& m, const void* E, int64_
 }
 
 hipError_t launch_mfma_f32(const MfmaF32Layout& m, int elem_type, const void* d_E, int64_t n_rows, int dim, const float* d_Q,
-                           int n_queries, int n_candidates, int space, char* ws, hipStream_t stream) {
+                           int n_queries, int n_candidates, int space, char* ws, hipStream_t stream, float thr_bias) {
   // normalised queries (fp32, or rounded to bf16 for a bf16 corpus), zero rows behind the real ones (a padding query
   // scores 0 everywhere; its threshold is forced to +inf in the kernel)
   // (l2: raw queries, rounded to bf16 for a bf16 corpus, and their squared norms)
@@ -690,13 +695,13 @@ hipError_t launch_mfma_f32(const MfmaF32Layout& m, int elem_type, const void* d_
 #define DEWI_DEPTH(CH)                                                                                                       \
   case CH:                                                                                                                   \
     if (l2) {                                                                                                                \
-      if (elem_type) return run_mfma_f32_dim<true, CH, true>(m, d_E, n_rows, n_queries, n_candidates, ws, stream);          \
+      if (elem_type) return run_mfma_f32_dim<true, CH, true>(m, d_E, n_rows, n_queries, n_candidates, ws, stream, 0.f);          \
       if constexpr (CH <= kF32MaxL2Chunks)                                                                                   \
-        return run_mfma_f32_dim<false, CH, true>(m, d_E, n_rows, n_queries, n_candidates, ws, stream);                       \
+        return run_mfma_f32_dim<false, CH, true>(m, d_E, n_rows, n_queries, n_candidates, ws, stream, 0.f);                       \
       return hipErrorInvalidValue;                                                                                           \
     }                                                                                                                        \
-    return elem_type ? run_mfma_f32_dim<true, CH, false>(m, d_E, n_rows, n_queries, n_candidates, ws, stream)                \
-                     : run_mfma_f32_dim<false, CH, false>(m, d_E, n_rows, n_queries, n_candidates, ws, stream);
+    return elem_type ? run_mfma_f32_dim<true, CH, false>(m, d_E, n_rows, n_queries, n_candidates, ws, stream, thr_bias)      \
+                     : run_mfma_f32_dim<false, CH, false>(m, d_E, n_rows, n_queries, n_candidates, ws, stream, thr_bias);
   switch (dim / kF32ChunkCols) {
     DEWI_DEPTH(1)
     DEWI_DEPTH(2)

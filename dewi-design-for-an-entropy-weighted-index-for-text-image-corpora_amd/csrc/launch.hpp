@@ -145,9 +145,11 @@ struct MfmaF32Layout {
 bool mfma_f32_path_supported(int elem_type, int64_t n_rows, int dim, int n_queries, int n_candidates, int space);
 // l2 over an fp32 corpus: |matrix-core score - (-||e - q||^2)| <= depth_l2_margin(dim) * (||e||^2 + ||q||^2)
 float depth_l2_margin(int dim);
-MfmaF32Layout plan_mfma_f32(int elem_type, int64_t n_rows, int dim, int n_queries, int n_candidates, int compute_units);
+MfmaF32Layout plan_mfma_f32(int elem_type, int64_t n_rows, int dim, int n_queries, int n_candidates, int compute_units,
+                            bool preselect = false);
+// thr_bias (cosine): subtracted from every threshold of the filter pass (pre-selection over a bf16 shadow: 2 * shadow_margin)
 hipError_t launch_mfma_f32(const MfmaF32Layout& m, int elem_type, const void* d_E, int64_t n_rows, int dim, const float* d_Q,
-                           int n_queries, int n_candidates, int space, char* ws, hipStream_t stream);
+                           int n_queries, int n_candidates, int space, char* ws, hipStream_t stream, float thr_bias = 0.f);
 
 // Per-query threshold = the n_candidates-th largest of each query's sample values (knn_mfma_bf16.hip).
 hipError_t launch_sample_threshold(const float* dense, int64_t n_sample, int64_t stride, int n_candidates, float* thr,

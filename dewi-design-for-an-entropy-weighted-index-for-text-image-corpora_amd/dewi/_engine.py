@@ -99,11 +99,11 @@ class DeviceCorpus:
         return DeviceCorpus(out, self.dewi32, self.ent32, self.space, self.id_offset)
 
     def enable_bf16_shadow(self) -> "DeviceCorpus":
-        """Keep a bf16 copy of this fp32 matrix next to it (+50 % memory).  Batches of more than 32 cosine queries then
-        run the 256-query matrix-core pass over the copy as a pre-selection — 256 queries per corpus pass over half the
-        bytes instead of 32 over all of them — and re-score the candidates from the fp32 rows with the row kernels'
-        arithmetic (``dewi_knn_rerank_f32_shadow``): results equal the one-query search bit for bit.  dim 256 / 512 / 768,
-        >= 64 K rows; any other shape simply takes the usual path."""
+        """Keep a bf16 copy of this fp32 matrix next to it (+50 % memory).  Batches of 2 or more cosine queries then run the
+        matrix-core passes over the copy as a PRE-SELECTION — half the bytes, and 256 queries per corpus pass instead of
+        32 for larger batches — and re-score the candidates from the fp32 rows with the row kernels' arithmetic
+        (``dewi_knn_rerank_f32_shadow``): results equal the one-query search bit for bit.  dim 256 / 512 / 768, >= 64 K
+        rows; any other shape simply takes the usual path."""
         torch = _torch()
         if self.is_bf16:
             raise ValueError("the corpus is already bf16")
@@ -209,7 +209,7 @@ class DeviceCorpus:
         if candidates is None and similarity != "ip":
             raise ValueError("similarity transforms belong to the ANN re-rank rule: pass candidates=k as well")
         ws = self._workspace(b, max(c, 1))
-        if candidates is None and self.shadow is not None and b > 32:
+        if candidates is None and self.shadow is not None and b >= 2:
             rc = self._lib.dewi_knn_rerank_f32_shadow(
                 nat.ptr(self.emb), nat.ptr(self.shadow), self.n_rows, self.dim, nat.ptr(q_dev), b, nat.ptr(self.dewi32),
                 nat.ptr(self.ent32), k, float(eta), float(entropy_pref), nat.SPACE_CODES[self.space], nat.ptr(out_ids),

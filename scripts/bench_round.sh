@@ -15,6 +15,8 @@ run c3 --config c3
 run c4 --config c4
 run c5 --config c5
 run c2_batch32 --batch 32 --steps 400 --warmup 100
+run c2_batch32_shadow --batch 32 --shadow 1 --steps 400 --warmup 100
+run c2_batch8_shadow --batch 8 --shadow 1 --steps 400 --warmup 100
 run c2_batch256_shadow --batch 256 --steps 400 --warmup 100
 run c2_batch256_shadow_k100 --batch 256 --k 100 --steps 400 --warmup 100
 DEWI_BENCH_FORCE_DIST=1 python3 bench.py --docs 125000 --steps 400 --warmup 40 --cpu-queries 0 > $OUT/bench_rccl_world1_125k.json 2> $OUT/bench_rccl_world1_125k.err

@@ -448,26 +448,28 @@ def test_bf16_dim768_shards_are_bit_equal_on_even_boundaries():
     assert torch.allclose(torch.sort(sc, dim=1).values, torch.sort(w_sc, dim=1).values, rtol=0, atol=1e-6)
 
 
-@pytest.mark.parametrize("dim,n,b,k", [(768, 70_000, 256, 10), (768, 100_003, 300, 100), (256, 131_072, 64, 50), (512, 66_000, 33, 1)])
+@pytest.mark.parametrize("dim,n,b,k", [(768, 70_000, 256, 10), (768, 100_003, 300, 100), (256, 131_072, 64, 50), (512, 66_000, 33, 1),
+                                       (768, 80_000, 32, 10), (512, 70_000, 2, 5), (256, 66_000, 8, 128), (768, 66_001, 5, 100)])
 def test_fp32_corpus_with_bf16_shadow_equals_the_one_query_search(dim, n, b, k):
-    """fp32 corpus + bf16 shadow (dewi_knn_rerank_f32_shadow): a batch of more than 32 cosine queries runs the 256-query
-    matrix-core pass over the shadow as a pre-selection and re-scores the candidates from the fp32 rows with the row
-    kernels' arithmetic — so it must equal the one-query fp32 searches BIT FOR BIT (ids and scores) and the oracle; the
-    plain fp32 batch path (32 queries per pass, three-piece cut) agrees up to its own summation order."""
+    """fp32 corpus + bf16 shadow (dewi_knn_rerank_f32_shadow): a batch of cosine queries runs a matrix-core pass over the
+    shadow as a pre-selection (2-32 queries: the depth-split pass in its bf16 geometry; more: the 256-query pass) and
+    re-scores the candidates from the fp32 rows with the row kernels' arithmetic — so it must equal the one-query fp32
+    searches BIT FOR BIT (ids and scores) and the oracle; the plain fp32 batch path (32 queries per pass, three-piece cut;
+    row kernels below 5 queries) agrees up to its own summation order."""
     import torch
     eng = _engine()
     raw = orc.synth_corpus(n, dim, seed=n % 1000 + dim)
     cols = orc.synth_payload_columns(n, seed=dim)
     Q = orc.synth_queries(b, dim, seed=b + k)
-    Q[3] = raw[77] * 3.0                                            # a scaled copy of a row: cosine 1
+    Q[min(3, b - 1)] = raw[77] * 3.0                                # a scaled copy of a row: cosine 1
     plain = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"])
     c = eng.DeviceCorpus(plain.emb, plain.dewi32, plain.ent32, "cosine").enable_bf16_shadow()
     assert c.shadow is not None and c.shadow.dtype == torch.bfloat16
     ids, sc = c.search(Q, k, 0.3, 0.1)
-    assert ids.min() >= 0 and ids[3][0] == 77 or k == 1
+    assert ids.min() >= 0
     E = plain.emb.cpu().numpy()
     dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
-    for j in sorted(set([0, 3, 31, 32, b // 2, b - 1])):
+    for j in sorted(set(j for j in (0, 3, 31, 32, b // 2, b - 1) if j < b)):
         i1, s1 = plain.search(Q[j], k, 0.3, 0.1)                     # one query: the row kernels
         assert np.array_equal(ids[j], i1[0]) and np.array_equal(sc[j], s1[0]), j
         _, msg = compare_query(E, Q[j], dewi32, ent32, k, 0.3, 0.1, "cosine", ids[j], sc[j], exact_gaps=False)
