@@ -276,11 +276,14 @@ def run_c2(args, torch, dist, eng, nat, rank, world, device):
     corpus = eng.DeviceCorpus(emb_raw, dewi32, ent32, "cosine", id_offset=lo)
     n_q = args.warmup + args.steps
     B = args.batch
-    shadowed = (B > 32 if args.shadow < 0 else (args.shadow == 1 and B >= 2)) and world == 1 and args.dim in (256, 512, 768)
+    # (the headline line — no flags, one query per step — never takes the shadow: it stays the plain fp32 scan over N*d*4 bytes)
+    shadowed = (B > 32 if args.shadow < 0 else args.shadow == 1) and world == 1 and args.dim in (256, 512, 768) and \
+        min(2 * args.k, total_rows) <= (512 if B > 32 else 256)
     if shadowed:
-        # batches of more than 32 queries over the fp32 corpus: 256-query pass over a bf16 shadow copy as a pre-selection,
-        # candidates re-scored from the fp32 rows (dewi_knn_rerank_f32_shadow): fp32-exact results, +50 % memory
-        corpus.enable_bf16_shadow()
+        # query batches over the fp32 corpus: a matrix-core pass over a bf16 shadow copy as a pre-selection, candidates
+        # re-scored from the fp32 rows (dewi_knn_rerank_f32_shadow): fp32-exact results, +50 % memory.  --shadow 1 with
+        # one query per step: the one-query search through the shadow (an extra line, never the default)
+        corpus.enable_bf16_shadow(single_query=(B == 1))
     qg = torch.Generator(device=device)
     qg.manual_seed(7)
     n_cpu = max(50, args.cpu_queries) if args.cpu_queries > 0 else 0
@@ -441,6 +444,12 @@ def run_c2(args, torch, dist, eng, nat, rank, world, device):
     kernel = ("scan_rows_f32" if (B < 5 and not shadowed) else f"mfma_scan_f32<false,{args.dim // 256},false,false>" if not shadowed
               else f"mfma_scan_bf16_s16<{args.dim // 16},false>" if B > 32 else f"mfma_scan_f32<true,{args.dim // 256},false,false>")
     traffic, traffic_note = recorded_traffic(f"{n_local}x{args.dim}x{elem}xB{B}", kernel)
+    if traffic is None and shadowed and B < 32:
+        # the depth-split pass is one launch of the same grid over the same rows for 1..32 active queries: the counter record
+        # taken with 32 stands for the smaller batches (and says so)
+        traffic, traffic_note = recorded_traffic(f"{n_local}x{args.dim}x{elem}xB32", kernel)
+        if traffic is not None:
+            traffic_note += f"; recorded with 32 queries per pass (same launch, {B} active here)"
 
     result = {
         "metric": METRIC,

@@ -426,11 +426,15 @@ size_t dewi_knn_workspace_bytes(int64_t n_rows, int dim, int n_queries, int n_ca
   const size_t b = layout_knn(n_rows, dim, 2, n_queries, n_candidates, dev.cus).total;
   if (b > a) a = b;
   if (dewi::mfma_path_supported(n_rows, dim, n_queries, n_candidates, DEWI_SPACE_COSINE)) {
-    const size_t m = dewi::plan_mfma(n_rows, dim, n_queries, n_candidates, dev.cus).total;
-    if (m > a) a = m;
+    for (int pre = 0; pre < 2; ++pre) {       // (pre = 1: pre-selection over a bf16 shadow — finer sample, other segment sizes)
+      const size_t m = dewi::plan_mfma(n_rows, dim, n_queries, n_candidates, dev.cus, pre != 0).total;
+      if (m > a) a = m;
+    }
   }
   for (int et = 0; et < 2; ++et) {
-    if (dewi::mfma_f32_path_supported(et, n_rows, dim, n_queries, n_candidates, DEWI_SPACE_COSINE)) {
+    // (a single query reaches the bf16 depth pass through the shadow entry: size for it as for two)
+    const int nq = et == 1 && n_queries < dewi::kMfmaMinQueries ? dewi::kMfmaMinQueries : n_queries;
+    if (dewi::mfma_f32_path_supported(et, n_rows, dim, nq, n_candidates, DEWI_SPACE_COSINE)) {
       for (int pre = 0; pre < 2; ++pre) {     // (pre = 1: the pass pre-selects over a bf16 shadow, finer sample)
         const size_t m = dewi::plan_mfma_f32(et, n_rows, dim, n_queries, n_candidates, dev.cus, pre != 0).total;
         if (m > a) a = m;
@@ -465,8 +469,12 @@ int dewi_knn_rerank_f32_shadow(const float* d_E, const uint16_t* d_E_bf16, int64
                       (dim == 256 || dim == 512 || dim == 768);
   const bool use_big = usable && n_queries > 32 && c64 <= 512 &&
                        dewi::mfma_path_supported(n_rows, dim, n_queries, static_cast<int>(c64), space);
+  // (a SINGLE query takes the depth-split pass too: one pass over half the bytes + the exact re-scoring, 0.26 ms instead of
+  // the fp32 row scan's 0.43 at 1 M x 768; the pass itself has no lower limit on the batch, kMfmaMinQueries is a choice
+  // between it and the bf16 row kernels for a bf16 CORPUS)
   const bool use_depth = usable && !use_big && c64 <= 256 &&
-                         dewi::mfma_f32_path_supported(1, n_rows, dim, n_queries, static_cast<int>(c64), space);
+                         dewi::mfma_f32_path_supported(1, n_rows, dim, n_queries < dewi::kMfmaMinQueries ? dewi::kMfmaMinQueries : n_queries,
+                                                       static_cast<int>(c64), space);
   if (!use_big && !use_depth)
     return knn_rerank_impl(d_E, 0, n_rows, dim, d_Q, n_queries, d_dewi32, d_ent32, k, eta, entropy_pref, space, d_out_ids,
                            d_out_scores, d_workspace, workspace_bytes, stream_);
@@ -479,7 +487,7 @@ int dewi_knn_rerank_f32_shadow(const float* d_E, const uint16_t* d_E_bf16, int64
     P.big = dewi::plan_mfma(n_rows, dim, n_queries, c, dev.cus, true);
     P.total = P.big.total;
   } else {
-    P.path = BatchPath::Depth;     // 2..32 queries (and larger batches the 256-query pass does not take): passes of 32 over the shadow
+    P.path = BatchPath::Depth;     // 1..32 queries (and larger batches the 256-query pass does not take): passes of 32 over the shadow
     P.depth = dewi::plan_mfma_f32(1, n_rows, dim, n_queries, c, dev.cus, true);
     P.total = P.depth.total;
   }

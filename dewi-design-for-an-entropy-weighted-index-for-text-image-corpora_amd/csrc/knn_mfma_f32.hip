@@ -439,7 +439,6 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
   };
 
   // l2 keeps the filter at the end of the iteration: it reads the row norms out of the reduction buffer, which the
-  // other waves refill at the end of the tile's last chunk (two chunks per tile: no barrier in between)
   // other waves refill at the end of the tile's last chunk (two chunks per tile: no barrier in between); with ONE chunk
   // per tile (dim 256) there is no later chunk of the same tile to move it to (the wave's own two registers of the
   // partial block, own0 / own1, are replaced at the end of the next iteration)

@@ -45,7 +45,8 @@ class DeviceCorpus:
         self._ws: Dict[Tuple[int, int], "torch.Tensor"] = {}
         self._q_pinned = None
         self._q_dev = None
-        self.shadow = None            # bf16 copy of an fp32 matrix (enable_bf16_shadow): pre-selection for batches > 32 queries
+        self.shadow = None            # bf16 copy of an fp32 matrix (enable_bf16_shadow): pre-selection over half the bytes
+        self.shadow_min_batch = 2     # smallest batch that goes through the shadow (enable_bf16_shadow(single_query=True): 1)
         self._io: Dict[Tuple[int, int], tuple] = {}      # (batch, k) -> device + pinned result buffers of search()
         # The blocking search() stages queries and results through per-instance buffers (pinned query, device
         # query, cached result buffers, workspaces): one caller at a time.  The reference's ExactIndex.search is
@@ -98,12 +99,17 @@ class DeviceCorpus:
                                                          nat.stream_ptr()))
         return DeviceCorpus(out, self.dewi32, self.ent32, self.space, self.id_offset)
 
-    def enable_bf16_shadow(self) -> "DeviceCorpus":
+    def enable_bf16_shadow(self, single_query: bool = False) -> "DeviceCorpus":
         """Keep a bf16 copy of this fp32 matrix next to it (+50 % memory).  Batches of 2 or more cosine queries then run the
         matrix-core passes over the copy as a PRE-SELECTION — half the bytes, and 256 queries per corpus pass instead of
         32 for larger batches — and re-score the candidates from the fp32 rows with the row kernels' arithmetic
         (``dewi_knn_rerank_f32_shadow``): results equal the one-query search bit for bit.  dim 256 / 512 / 768, >= 64 K
-        rows; any other shape simply takes the usual path."""
+        rows; any other shape simply takes the usual path.
+
+        ``single_query=True`` sends one-query searches through the shadow as well (same pass, same re-scoring, same
+        answers: 0.26 ms instead of 0.43 at 1 M x 768).  Off by default: ``search_device`` with one query is then no
+        longer "always answered" — like any matrix-core batch it may come back refused (id -1) on adversarial corpora;
+        the blocking ``search`` and ``PipelinedSearcher.drain`` repair such a query on the plain fp32 scan."""
         torch = _torch()
         if self.is_bf16:
             raise ValueError("the corpus is already bf16")
@@ -120,6 +126,7 @@ class DeviceCorpus:
             with torch.cuda.device(self.device):
                 nat.check(self._lib.dewi_convert_f32_to_bf16(nat.ptr(self.emb), nat.ptr(out), self.emb.numel(), nat.stream_ptr()))
             self.shadow = out
+        self.shadow_min_batch = 1 if single_query else 2
         return self
 
     # ------------------------------------------------------------------ properties
@@ -174,7 +181,7 @@ class DeviceCorpus:
 
     # ------------------------------------------------------------------ hot path
     def search_device(self, q_dev, k: int, eta: float, entropy_pref: float, out_ids=None, out_scores=None,
-                      candidates: Optional[int] = None, similarity: str = "ip"):
+                      candidates: Optional[int] = None, similarity: str = "ip", use_shadow: bool = True):
         """Enqueue one search on the current stream; returns device tensors, no sync.
 
         q_dev: fp32 [B, d] on this device (raw queries; cosine normalisation happens in-kernel).
@@ -188,8 +195,8 @@ class DeviceCorpus:
         bf16 corpus a batch of >= 2 queries takes the matrix-core path, which marks a query whose
         survivor buffer overflowed (adversarial corpora only) with id -1 / score NaN in every slot.
         Callers that keep results on the device must check ``unanswered(ids)`` after synchronising
-        and re-run those queries one at a time (a single query always takes the exact kernels);
-        the blocking ``search`` and ``PipelinedSearcher.drain`` do that.
+        and re-run those queries one at a time with ``use_shadow=False`` (a single query then always
+        takes the exact kernels); the blocking ``search`` and ``PipelinedSearcher.drain`` do that.
         """
         torch = _torch()
         b = int(q_dev.shape[0])
@@ -209,7 +216,7 @@ class DeviceCorpus:
         if candidates is None and similarity != "ip":
             raise ValueError("similarity transforms belong to the ANN re-rank rule: pass candidates=k as well")
         ws = self._workspace(b, max(c, 1))
-        if candidates is None and self.shadow is not None and b >= 2:
+        if candidates is None and self.shadow is not None and b >= self.shadow_min_batch and use_shadow:
             rc = self._lib.dewi_knn_rerank_f32_shadow(
                 nat.ptr(self.emb), nat.ptr(self.shadow), self.n_rows, self.dim, nat.ptr(q_dev), b, nat.ptr(self.dewi32),
                 nat.ptr(self.ent32), k, float(eta), float(entropy_pref), nat.SPACE_CODES[self.space], nat.ptr(out_ids),
@@ -242,7 +249,8 @@ class DeviceCorpus:
         redo = self.unanswered(ids_host)
         for j in redo.tolist():
             sub = q_dev[j:j + 1].contiguous()
-            i2, s2 = self.search_device(sub, k, eta, entropy_pref, candidates=candidates, similarity=similarity)
+            i2, s2 = self.search_device(sub, k, eta, entropy_pref, candidates=candidates, similarity=similarity,
+                                        use_shadow=False)
             ids_host[j] = i2.cpu().numpy()[0]
             scores_host[j] = s2.cpu().numpy()[0]
         return int(len(redo))
@@ -400,7 +408,7 @@ class PipelinedSearcher:
                     row_ids = out_ids.view(self.b, -1)[j:j + 1]
                     self.corpus.search_device(q_dev[j:j + 1].contiguous(), self.k, self.eta, self.pref,
                                               row_ids, out_scores.view(self.b, -1)[j:j + 1],
-                                              candidates=self.c if self._explicit_c else None)
+                                              candidates=self.c if self._explicit_c else None, use_shadow=False)
                     if self.corpus.id_offset:          # dewi_knn_finish wrote the other rows with the shard's id offset;
                         row_ids += self.corpus.id_offset   # the one-call search answers in local rows
             torch.cuda.current_stream().synchronize()

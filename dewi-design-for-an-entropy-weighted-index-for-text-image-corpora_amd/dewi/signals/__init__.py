@@ -109,7 +109,7 @@ def redundancy_top1(text_emb, image_emb, batch: int = 1024, bf16: Optional[bool]
         out_dev[s:e] = torch.where(own, sims[:, 1], sims[:, 0])
         bad_dev[s:e] = ids[:, 0] < 0                                   # batched bf16 path overflowed for that query
     for i in torch.nonzero(bad_dev).flatten().tolist():               # adversarial corpora only: exact re-run
-        ids, sims = corpus.search_device(t_dev[i:i + 1].contiguous(), 2, 0.0, 0.0)
+        ids, sims = corpus.search_device(t_dev[i:i + 1].contiguous(), 2, 0.0, 0.0, use_shadow=False)
         out_dev[i] = torch.where(ids[0, 0] == i, sims[0, 1], sims[0, 0])
     return out_dev if return_device else out_dev.cpu().numpy()
 

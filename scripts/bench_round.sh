@@ -2,7 +2,8 @@
 # The round's bench lines WITHOUT a profiler attached (run from the repo root on the GPU box, after profile_round.sh so that
 # profiles/hbm_traffic.json matches these sources):   bash scripts/bench_round.sh <tag>
 # One JSON line per file under gpurun_out/bench_<tag>/: the default command (config C2), the driver's form (--steps 20
-# --warmup 5), C3, C4, C5, 32 / 256 queries per step over the C2 corpus (256: bf16 shadow + exact re-scoring), and the
+# --warmup 5), C3, C4, C5, 32 / 256 queries per step over the C2 corpus, the bf16-shadow legs (1 / 8 / 32 / 256 queries per
+# step: pre-selection over the shadow + exact re-scoring; the one-query leg is an extra line, not the headline), and the
 # single-GPU rehearsal of the sharded loop.
 set -e
 TAG=${1:-r03}
@@ -17,6 +18,7 @@ run c5 --config c5
 run c2_batch32 --batch 32 --steps 400 --warmup 100
 run c2_batch32_shadow --batch 32 --shadow 1 --steps 400 --warmup 100
 run c2_batch8_shadow --batch 8 --shadow 1 --steps 400 --warmup 100
+run c2_batch1_shadow --batch 1 --shadow 1
 run c2_batch256_shadow --batch 256 --steps 400 --warmup 100
 run c2_batch256_shadow_k100 --batch 256 --k 100 --steps 400 --warmup 100
 DEWI_BENCH_FORCE_DIST=1 python3 bench.py --docs 125000 --steps 400 --warmup 40 --cpu-queries 0 > $OUT/bench_rccl_world1_125k.json 2> $OUT/bench_rccl_world1_125k.err

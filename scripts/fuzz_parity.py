@@ -46,7 +46,7 @@ def one_search_case(i):
         n = int(rs.randint(65_536, 160_000))
         bf16 = bool(rs.rand() < 0.45)
         space = "l2" if rs.rand() < 0.2 else "cosine"
-        b = int(rs.choice([2, 5, 8, 31, 32, 33, 64, 65, 100, 256, 257, 300]))
+        b = int(rs.choice([1, 1, 2, 5, 8, 31, 32, 33, 64, 65, 100, 256, 257, 300]))
         k = int(rs.choice([1, 5, 10, 50, 100, 128, 129, 300, 1000]))
     else:
         dim = int(rs.choice(DIMS))
@@ -74,8 +74,8 @@ def one_search_case(i):
         kw = dict(gap=1e-6, score_tol=1e-5, prepared=True)
     else:
         E, Qo = c.emb.cpu().numpy(), Q
-        if space == "cosine" and dim in (256, 512, 768) and b > 32 and rs.rand() < 0.7:
-            c.enable_bf16_shadow()          # batches > 32: 256-query pass over the bf16 shadow + exact re-scoring
+        if space == "cosine" and dim in (256, 512, 768) and rs.rand() < 0.7:
+            c.enable_bf16_shadow(single_query=True)   # matrix-core pass over the bf16 shadow + exact re-scoring (1+ queries)
             LAST.update(shadow=True)
             done["shadow"] = done.get("shadow", 0) + 1
     ids, sc = c.search(Q, k, eta, pref)

@@ -449,7 +449,8 @@ def test_bf16_dim768_shards_are_bit_equal_on_even_boundaries():
 
 
 @pytest.mark.parametrize("dim,n,b,k", [(768, 70_000, 256, 10), (768, 100_003, 300, 100), (256, 131_072, 64, 50), (512, 66_000, 33, 1),
-                                       (768, 80_000, 32, 10), (512, 70_000, 2, 5), (256, 66_000, 8, 128), (768, 66_001, 5, 100)])
+                                       (768, 80_000, 32, 10), (512, 70_000, 2, 5), (256, 66_000, 8, 128), (768, 66_001, 5, 100),
+                                       (768, 120_526, 65, 129)])   # (last: the pre-selection's own workspace size, a fuzz find)
 def test_fp32_corpus_with_bf16_shadow_equals_the_one_query_search(dim, n, b, k):
     """fp32 corpus + bf16 shadow (dewi_knn_rerank_f32_shadow): a batch of cosine queries runs a matrix-core pass over the
     shadow as a pre-selection (2-32 queries: the depth-split pass in its bf16 geometry; more: the 256-query pass) and
@@ -478,6 +479,70 @@ def test_fp32_corpus_with_bf16_shadow_equals_the_one_query_search(dim, n, b, k):
     assert np.mean(ids_p == ids) > 0.98 and np.allclose(np.sort(sc_p, axis=1), np.sort(sc, axis=1), rtol=0, atol=2e-6)
     ids2, sc2 = c.search(Q, k, 0.3, 0.1)                             # deterministic
     assert np.array_equal(ids2, ids) and np.array_equal(sc2, sc)
+
+
+@pytest.mark.parametrize("dim,n,k", [(768, 70_000, 10), (256, 131_073, 128), (512, 66_000, 1)])
+def test_one_query_through_the_bf16_shadow_equals_the_fp32_row_scan(dim, n, k):
+    """enable_bf16_shadow(single_query=True): ONE query runs the depth-split pass over the shadow + the exact re-scoring;
+    ids and scores equal the plain fp32 one-query search bit for bit, for many queries (incl. an exact copy of a row),
+    through the blocking API and on device tensors; without the switch one query keeps the fp32 row scan."""
+    import torch
+    eng = _engine()
+    raw = orc.synth_corpus(n, dim, seed=n % 1000 + dim + 1)
+    cols = orc.synth_payload_columns(n, seed=dim + 1)
+    Q = orc.synth_queries(24, dim, seed=k + 5)
+    Q[5] = raw[4242] * 0.5
+    plain = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    c = eng.DeviceCorpus(plain.emb, plain.dewi32, plain.ent32, "cosine").enable_bf16_shadow(single_query=True)
+    assert c.shadow_min_batch == 1
+    E = plain.emb.cpu().numpy()
+    dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    for j in range(24):
+        ids, sc = c.search(Q[j], k, 0.3, 0.1)
+        i1, s1 = plain.search(Q[j], k, 0.3, 0.1)
+        assert ids.shape == (1, k) and ids.min() >= 0
+        assert np.array_equal(ids, i1) and np.array_equal(sc, s1), j
+        if j < 6:
+            _, msg = compare_query(E, Q[j], dewi32, ent32, k, 0.3, 0.1, "cosine", ids[0], sc[0], exact_gaps=False)
+            assert msg is None, (j, msg)
+    qd = torch.from_numpy(Q).cuda()
+    d_ids, d_sc = c.search_device(qd[5:6].contiguous(), k, 0.3, 0.1)
+    p_ids, p_sc = c.search_device(qd[5:6].contiguous(), k, 0.3, 0.1, use_shadow=False)
+    assert torch.equal(d_ids, p_ids) and torch.equal(d_sc, p_sc)
+    assert int(d_ids[0, 0]) == 4242 or k > 1                          # eta = 0.3: the copy leads unless DEWI outweighs it
+    two = eng.DeviceCorpus(plain.emb, plain.dewi32, plain.ent32, "cosine").enable_bf16_shadow()
+    assert two.shadow_min_batch == 2
+    # the one-query call really reads the shadow: with the shadow zeroed every row ties at 0, the survivors overflow and the
+    # raw call comes back refused — while the corpus without the switch (and the repair inside search()) never looks at it
+    c.shadow.zero_()
+    z_ids, _ = c.search_device(qd[5:6].contiguous(), k, 0.3, 0.1)
+    assert int(z_ids[0, 0]) == -1
+    two.shadow.zero_()
+    t_ids, t_sc = two.search_device(qd[5:6].contiguous(), k, 0.3, 0.1)
+    assert torch.equal(t_ids, p_ids) and torch.equal(t_sc, p_sc)
+    ids, sc = c.search(Q[5], k, 0.3, 0.1)
+    assert np.array_equal(ids, p_ids.cpu().numpy()) and np.array_equal(sc, p_sc.cpu().numpy())
+
+
+def test_one_query_through_the_shadow_is_repaired_when_the_pass_refuses_it():
+    """A corpus with 20 000 copies of one row: the pre-selection's survivors of a query that points at them overflow the
+    segment, the pass refuses the query (id -1), and search() answers it on the plain fp32 scan — the same answer as
+    the unshadowed corpus gives."""
+    import torch
+    eng = _engine()
+    n, dim, k = 90_000, 256, 10
+    raw = orc.synth_corpus(n, dim, seed=77)
+    raw[10_000:30_000] = raw[5]
+    cols = orc.synth_payload_columns(n, seed=78)
+    plain = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    c = eng.DeviceCorpus(plain.emb, plain.dewi32, plain.ent32, "cosine").enable_bf16_shadow(single_query=True)
+    q = raw[5] * 2.0
+    raw_ids, _ = c.search_device(torch.from_numpy(q[None]).cuda(), k, 0.3, 0.1)
+    ids, sc = c.search(q, k, 0.3, 0.1)
+    i1, s1 = plain.search(q, k, 0.3, 0.1)
+    assert ids.min() >= 0 and np.array_equal(ids, i1) and np.array_equal(sc, s1)
+    # (whether the raw call was refused depends on the segment capacity; either way the blocking answer is the exact one)
+    assert int(raw_ids[0, 0]) == -1 or np.array_equal(raw_ids.cpu().numpy(), i1)
 
 
 def test_bf16_shadow_refuses_rows_that_are_not_normalised():
