@@ -144,6 +144,8 @@ class ExactIndex(BaseIndex):
         # additive: keep a bf16 shadow copy of the fp32 matrix (+50 % HBM) so that search_batch with more than 32 queries
         # runs 256 queries per corpus pass as a pre-selection and re-scores exactly (DeviceCorpus.enable_bf16_shadow)
         self._batch_shadow: bool = bool(kwargs.get("batch_shadow", False))
+        # with batch_shadow: search() of ONE query goes through the shadow too (same answers; see enable_bf16_shadow)
+        self._shadow_single: bool = bool(kwargs.get("shadow_single_query", False))
 
     # ---------------------------------------------------------------- ingest (A1)
     def add(self, doc_id: str, embedding: np.ndarray, payload: Payload) -> None:
@@ -298,7 +300,7 @@ class ExactIndex(BaseIndex):
             torch.cuda.current_stream().synchronize()
         self._corpus = DeviceCorpus(emb, dewi32, ent32, self.space)
         if self._batch_shadow and self.space == "cosine":
-            self._corpus.enable_bf16_shadow()
+            self._corpus.enable_bf16_shadow(single_query=self._shadow_single)
         self._pending = []
         self._pending_rows = 0
         self._loaded_rows = None
@@ -332,7 +334,8 @@ class ExactIndex(BaseIndex):
                                                                          nat.stream_ptr()))
                     torch.cuda.current_stream().synchronize()
             corpus = head
-        self._corpus = corpus.enable_bf16_shadow() if self._batch_shadow and self.space == "cosine" else corpus
+        self._corpus = (corpus.enable_bf16_shadow(single_query=self._shadow_single)
+                        if self._batch_shadow and self.space == "cosine" else corpus)
         self._pending = []
         self._pending_rows = 0
         self._loaded_rows = None

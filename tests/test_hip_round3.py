@@ -524,6 +524,42 @@ def test_one_query_through_the_bf16_shadow_equals_the_fp32_row_scan(dim, n, k):
     assert np.array_equal(ids, p_ids.cpu().numpy()) and np.array_equal(sc, p_sc.cpu().numpy())
 
 
+def test_exact_index_with_batch_shadow_answers_as_the_plain_index():
+    """ExactIndex(batch_shadow=True[, shadow_single_query=True]) — the reference's API (backends.py:369-481: add / build /
+    search) with the additive switches: search() and search_batch() return what the plain index returns, id for id and bit
+    for bit, whether the rows arrive as host arrays or as a device block."""
+    import torch
+    from dewi.index import ExactIndex
+    n, dim, k = 70_000, 256, 10
+    raw = orc.synth_corpus(n, dim, seed=91)
+    cols = orc.synth_payload_columns(n, seed=92)
+    ids = [f"d{i}" for i in range(n)]
+    Q = orc.synth_queries(40, dim, seed=93)
+    plain = ExactIndex(dim=dim, space="cosine")
+    plain.add_batch_columns(ids, raw, cols)
+    plain.build()
+    want_rows, want_sc = plain.search_batch(Q, k=k, eta=0.3, entropy_pref=0.1)
+    for single, on_device in ((False, False), (True, False), (True, True)):
+        idx = ExactIndex(dim=dim, space="cosine", batch_shadow=True, shadow_single_query=single)
+        if on_device:
+            idx.add_batch_columns(ids, torch.from_numpy(raw).cuda(), {kk: torch.from_numpy(np.asarray(v)).cuda() for kk, v in cols.items()})
+        else:
+            idx.add_batch_columns(ids, raw, cols)
+        idx.build()
+        assert idx._corpus.shadow is not None and idx._corpus.shadow_min_batch == (1 if single else 2)
+        rows, sc = idx.search_batch(Q, k=k, eta=0.3, entropy_pref=0.1)
+        assert np.array_equal(rows, want_rows) and np.array_equal(sc, want_sc)
+        for j in (0, 7):
+            got = idx.search(Q[j], k=k, eta=0.3, entropy_pref=0.1)
+            ref = plain.search(Q[j], k=k, eta=0.3, entropy_pref=0.1)
+            assert [r[0] for r in got] == [r[0] for r in ref] and [r[1] for r in got] == [r[1] for r in ref]
+            assert [r[0] for r in got] == [ids[r] for r in want_rows[j]]
+    l2 = ExactIndex(dim=dim, space="l2", batch_shadow=True)          # the switch is a no-op outside cosine
+    l2.add_batch_columns(ids[:1000], raw[:1000], {kk: np.asarray(v)[:1000] for kk, v in cols.items()})
+    l2.build()
+    assert l2._corpus.shadow is None
+
+
 def test_one_query_through_the_shadow_is_repaired_when_the_pass_refuses_it():
     """A corpus with 20 000 copies of one row: the pre-selection's survivors of a query that points at them overflow the
     segment, the pass refuses the query (id -1), and search() answers it on the plain fp32 scan — the same answer as
