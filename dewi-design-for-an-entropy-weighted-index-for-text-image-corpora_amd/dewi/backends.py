@@ -141,8 +141,9 @@ class ExactIndex(BaseIndex):
         self._host_rows: Optional[np.ndarray] = None  # lazily materialised copy of the stored matrix
         self._loaded_rows: Optional[np.ndarray] = None  # rows read by load(): already in stored form
         self._device: Optional[str] = kwargs.get("device")
-        # additive: keep a bf16 shadow copy of the fp32 matrix (+50 % HBM) so that search_batch with more than 32 queries
-        # runs 256 queries per corpus pass as a pre-selection and re-scores exactly (DeviceCorpus.enable_bf16_shadow)
+        # additive: keep a bf16 shadow copy of the fp32 matrix (+50 % HBM): search_batch then runs a matrix-core pass over the
+        # copy as a pre-selection (half the bytes; 256 queries per corpus pass above 32) and re-scores the candidates from the
+        # fp32 rows — same ids and scores as the one-query search (DeviceCorpus.enable_bf16_shadow)
         self._batch_shadow: bool = bool(kwargs.get("batch_shadow", False))
         # with batch_shadow: search() of ONE query goes through the shadow too (same answers; see enable_bf16_shadow)
         self._shadow_single: bool = bool(kwargs.get("shadow_single_query", False))
