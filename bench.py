@@ -441,10 +441,13 @@ def run_c2(args, torch, dist, eng, nat, rank, world, device):
     achieved = algo_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     # --batch >= 5 over the fp32 corpus: the depth-split matrix-core pass is the dominant kernel (one per 32 queries);
     # --batch > 32: the 256-query pass over the bf16 shadow (one per 256 queries)
+    # --batch 1 --shadow 1 (cut of at most 32 rows): the bf16 ROW kernel over the shadow
     kernel = ("scan_rows_f32" if (B < 5 and not shadowed) else f"mfma_scan_f32<false,{args.dim // 256},false,false>" if not shadowed
-              else f"mfma_scan_bf16_s16<{args.dim // 16},false>" if B > 32 else f"mfma_scan_f32<true,{args.dim // 256},false,false>")
+              else f"mfma_scan_bf16_s16<{args.dim // 16},false>" if B > 32
+              else f"scan_rows_bf16<{args.dim // 256},1,0,1,true>" if (B == 1 and c <= 32)
+              else f"mfma_scan_f32<true,{args.dim // 256},false,false>")
     traffic, traffic_note = recorded_traffic(f"{n_local}x{args.dim}x{elem}xB{B}", kernel)
-    if traffic is None and shadowed and B < 32:
+    if traffic is None and shadowed and B < 32 and kernel.startswith("mfma_scan_f32"):
         # the depth-split pass is one launch of the same grid over the same rows for 1..32 active queries: the counter record
         # taken with 32 stands for the smaller batches (and says so)
         traffic, traffic_note = recorded_traffic(f"{n_local}x{args.dim}x{elem}xB32", kernel)

@@ -425,6 +425,10 @@ size_t dewi_knn_workspace_bytes(int64_t n_rows, int dim, int n_queries, int n_ca
   size_t a = layout_knn(n_rows, dim, 4, n_queries, n_candidates, dev.cus).total;
   const size_t b = layout_knn(n_rows, dim, 2, n_queries, n_candidates, dev.cus).total;
   if (b > a) a = b;
+  if (const int ll = dewi::shadow_list_len(n_candidates)) {   // one query through the bf16 shadow: longer per-workgroup lists
+    const size_t s = layout_knn(n_rows, dim, 2, n_queries, ll, dev.cus).total;
+    if (s > a) a = s;
+  }
   if (dewi::mfma_path_supported(n_rows, dim, n_queries, n_candidates, DEWI_SPACE_COSINE)) {
     for (int pre = 0; pre < 2; ++pre) {       // (pre = 1: pre-selection over a bf16 shadow — finer sample, other segment sizes)
       const size_t m = dewi::plan_mfma(n_rows, dim, n_queries, n_candidates, dev.cus, pre != 0).total;
@@ -475,6 +479,27 @@ int dewi_knn_rerank_f32_shadow(const float* d_E, const uint16_t* d_E_bf16, int64
   const bool use_depth = usable && !use_big && c64 <= 256 &&
                          dewi::mfma_f32_path_supported(1, n_rows, dim, n_queries < dewi::kMfmaMinQueries ? dewi::kMfmaMinQueries : n_queries,
                                                        static_cast<int>(c64), space);
+  // ONE query with a small cut: the bf16 ROW kernel over the shadow (two launches instead of the pass's five: 0.222 ms scan
+  // at 1 M x 768) with per-workgroup lists long enough for the rows inside the error band, then the same exact re-scoring
+  // (select_rerank.hip refine_from_sorted_lists)
+  const int list_len = (usable && n_queries == 1 && n_rows >= 64 * 1024) ? dewi::shadow_list_len(static_cast<int>(c64 < 64 ? c64 : 64)) : 0;
+  if (list_len > 0) {
+    if (!d_dewi32 || !d_ent32 || !d_out_ids || !d_out_scores) return fail(DEWI_ERR_INVALID_ARG, "null payload or output pointer");
+    const KnnLayout L = layout_knn(n_rows, dim, 2, 1, list_len, dev.cus);
+    if (L.plan.fast && L.plan.slots == 1 && L.plan.n_lists <= 4 * 64) {
+      if (!d_workspace || workspace_bytes < L.total)
+        return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, L.total);
+      char* ws = static_cast<char*>(d_workspace);
+      rc = run_scan(L, d_E_bf16, 1, n_rows, dim, d_Q, 1, list_len, space, ws, stream);
+      if (rc) return rc;
+      const dewi::RefineParams rf{d_E, d_Q, nullptr, dim, dewi::shadow_margin(dim), DEWI_SPACE_COSINE, list_len};
+      const hipError_t e = dewi::launch_select_rerank(reinterpret_cast<const uint64_t*>(ws + L.keys_off), L.plan.keys_per_query,
+                                                      L.plan.n_lists, 1, static_cast<int>(c64), k,
+                                                      make_rerank(eta, entropy_pref, DEWI_SIM_RAW, space), d_dewi32, d_ent32, 0,
+                                                      d_out_ids, d_out_scores, nullptr, nullptr, dewi::SegmentLayout{}, stream, rf);
+      return e == hipSuccess ? DEWI_OK : hip_fail(e, "select launch (one query, bf16 shadow)");
+    }
+  }
   if (!use_big && !use_depth)
     return knn_rerank_impl(d_E, 0, n_rows, dim, d_Q, n_queries, d_dewi32, d_ent32, k, eta, entropy_pref, space, d_out_ids,
                            d_out_scores, d_workspace, workspace_bytes, stream_);

@@ -190,7 +190,16 @@ struct RefineParams {
   int dim;               // 256, 512 or 768
   float margin;          // l2: depth_l2_margin(dim), the bound per unit of ||e||^2 + ||q||^2; cosine: the bound itself
   int space;             // DEWI_SPACE_*
+  int list_len;          // > 0: the keys are `sorted_lists` sorted lists of THIS length from a row kernel over the bf16 shadow
+                         // (one query; n_candidates is then only the cut c <= list_len), see refine_from_sorted_lists
 };
+// one query through the bf16 shadow on the bf16 ROW kernel: length of the per-workgroup lists it is asked for (the cut's c plus
+// room for the rows inside the error band: ~0.2 per workgroup at 1 M gaussian rows; lists of 32 instead of 40 at c = 20 were
+// no faster: 0.2306 vs 0.2282 ms scan on two boxes), 0 = this route does not serve that cut
+inline int shadow_list_len(int n_candidates) {
+  if (n_candidates > 32) return 0;
+  return n_candidates <= 16 ? 32 : 2 * n_candidates;
+}
 hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, int sorted_lists, int n_queries,
                                 int n_candidates, int k, const RerankParams& rp, const float* d_dewi32, const float* d_ent32,
                                 int64_t id_offset, int64_t* d_out_ids, float* d_out_scores,

@@ -266,6 +266,66 @@ __device__ __forceinline__ int refine_from_segments(const SegmentKeys& kv, uint6
   return refine_rescore(scratch, n_candidates, sh, rf, q);
 }
 
+// ONE query whose approximate scores come from the bf16 ROW kernel over the bf16 shadow of an fp32 corpus (cosine): `n_lists`
+// (<= 256, one per workgroup of the scan) lists of `list_len` keys, each sorted descending, list_len >= c.
+//   a0 = the c-th largest of 64 lane maxima of the list heads: a lower bound of a_c, the c-th best approximate score;
+//   a row of the exact top c has exact >= a_c - M (c rows do), so approximate >= a_c - 2M >= a0 - 2M =: low — every key at or
+//   above `low` is a candidate (a superset of refine_top_candidates' set: the band hangs below a0 instead of a_c);
+//   a list holds its workgroup's best list_len rows: if ALL of them are candidates the workgroup may have dropped one, and the
+//   query is refused (-2: adversarial corpora — thousands of near-copies of one row; the caller repeats it on the fp32 scan).
+// Four threads per list walk it together (sorted: once nothing of a wave passes, nothing later does).
+__device__ __forceinline__ int refine_from_sorted_lists(const uint64_t* __restrict__ keys, int n_lists, int list_len, int n_candidates,
+                                                        SelectShared& sh, uint64_t* scratch, const RefineParams& rf, int q) {
+  const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
+  const int lane = tid & 63;
+  if (tid == 0) {
+    sh.count = 0;
+    sh.total = 0;
+    sh.bound = 1ull;
+  }
+  __syncthreads();
+  if (tid < kWave) {
+    uint64_t lane_max = kKeyEmpty;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int l = tid + kWave * u;
+      const uint64_t m = l < n_lists ? keys[static_cast<int64_t>(l) * list_len] : kKeyEmpty;
+      lane_max = m > lane_max ? m : lane_max;
+    }
+    const uint32_t mh = static_cast<uint32_t>(lane_max >> 32), ml = static_cast<uint32_t>(lane_max);
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < kWave; ++j) {
+      const uint64_t o = (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mh), j))) << 32) |
+                         static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ml), j));
+      rank += (o > lane_max || (o == lane_max && j < tid)) ? 1 : 0;
+    }
+    // (fewer than c non-empty lanes: no bound, every key is a candidate)
+    if (rank == n_candidates - 1 && lane_max != kKeyEmpty) sh.bound = lane_max;
+  }
+  __syncthreads();
+  const uint64_t bound = sh.bound;
+  const float low = bound == 1ull ? -__builtin_inff() : key_score(bound) - 2.f * rf.margin;
+  constexpr int kGroup = 4;
+  const int sub = tid % kGroup;
+  const int steps = (list_len + kGroup - 1) / kGroup;
+  for (int l0 = 0; l0 < n_lists; l0 += nt / kGroup) {
+    const int l = l0 + tid / kGroup;
+    for (int st = 0; st < steps; ++st) {
+      const int j = st * kGroup + sub;
+      const uint64_t key = (l < n_lists && j < list_len) ? keys[static_cast<int64_t>(l) * list_len + j] : kKeyEmpty;
+      const float a = key_score(key);
+      const bool pass = key != kKeyEmpty && !(a < low);      // NaN scores pass (NaN rows rank first)
+      if (pass && j == list_len - 1) sh.total = 1;            // the whole list is inside the band
+      if (__builtin_amdgcn_ballot_w64(pass) == 0ull) break;
+      refine_append(sh, pass, key, lane);
+    }
+  }
+  __syncthreads();
+  if (sh.total) return -2;
+  return refine_rescore(scratch, n_candidates, sh, rf, q);
+}
+
 // Part 2: sh.count candidates in sh.sel2 -> exact scores -> the best n_candidates, sorted, in sh.sel.
 __device__ __forceinline__ int refine_rescore(uint64_t* keys, int n_candidates, SelectShared& sh, const RefineParams& rf, int q) {
   const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
@@ -509,6 +569,23 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(
   const int q = static_cast<int>(blockIdx.x);
   const uint64_t* keys = keys_all + static_cast<int64_t>(q) * keys_per_query;
   int n_sel;
+  auto refuse = [&]() {            // ids -1 / records -2: the documented marker of a query the approximate pass could not answer
+    if (out_cand != nullptr) {   // shard mode: every record of this query carries the marker id -2
+      for (int j = tid; j < n_candidates; j += nt) {
+        dewi_candidate rec;
+        rec.sim = __builtin_nanf("");
+        rec.dewi = 0.f;
+        rec.ent = 0.f;
+        rec.id = -2;
+        out_cand[static_cast<int64_t>(q) * n_candidates + j] = rec;
+      }
+      return;
+    }
+    for (int j = tid; j < k; j += nt) {
+      out_ids[static_cast<int64_t>(q) * k + j] = -1;
+      out_scores[static_cast<int64_t>(q) * k + j] = __builtin_nanf("");
+    }
+  };
   if (counts != nullptr) {
     // Output of the batched matrix-core scan: `seg.n_seg` per-workgroup segments.  A count above the
     // segment capacity means that buffer overflowed and this query was NOT answered: the caller
@@ -519,23 +596,6 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(
     __shared__ WideRadixShared ws;
     __shared__ uint32_t seg_base[kSelectThreads], seg_cnt[kSelectThreads];
     const uint32_t cap = static_cast<uint32_t>(seg.cap);
-    auto refuse = [&]() {
-      if (out_cand != nullptr) {   // shard mode: every record of this query carries the marker id -2
-        for (int j = tid; j < n_candidates; j += nt) {
-          dewi_candidate rec;
-          rec.sim = __builtin_nanf("");
-          rec.dewi = 0.f;
-          rec.ent = 0.f;
-          rec.id = -2;
-          out_cand[static_cast<int64_t>(q) * n_candidates + j] = rec;
-        }
-        return;
-      }
-      for (int j = tid; j < k; j += nt) {
-        out_ids[static_cast<int64_t>(q) * k + j] = -1;
-        out_scores[static_cast<int64_t>(q) * k + j] = __builtin_nanf("");
-      }
-    };
     if (tid == 0) sh.total = 0;
     __syncthreads();
     if (seg.n_seg <= nt && seg.raw != 0) {
@@ -635,6 +695,13 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(
         n_sel = exact_top_candidates(ArrayKeys{dyn_keys, static_cast<int64_t>(total)}, n_candidates, sh);
       else
         n_sel = exact_top_candidates(kv, n_candidates, sh);
+    }
+  } else if (refine.E != nullptr && refine.list_len > 0) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t dyn_scratch[];     // kMaxSortCandidates keys (launcher)
+    n_sel = refine_from_sorted_lists(keys, sorted_lists, refine.list_len, n_candidates, sh, dyn_scratch, refine, q);
+    if (n_sel == -2) {
+      refuse();
+      return;
     }
   } else {
     n_sel = gather_top_candidates(keys, keys_per_query, sorted_lists, n_candidates, sh);
@@ -959,12 +1026,17 @@ hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, 
                                 dewi_candidate* d_out_cand, const uint32_t* d_counts, const SegmentLayout& seg,
                                 hipStream_t stream, const RefineParams& refine) {
   int threads = kSelectThreads;
-  if (sorted_lists > 0) {
+  const bool refine_lists = refine.E != nullptr && refine.list_len > 0;   // one query through the shadow on the row kernel
+  if (refine_lists) {
+    if (d_counts != nullptr || sorted_lists <= 0 || sorted_lists > 4 * kWave || refine.list_len > kWave ||
+        n_candidates > refine.list_len || refine.space != DEWI_SPACE_COSINE)
+      return hipErrorInvalidValue;
+  } else if (sorted_lists > 0) {
     threads = sorted_lists <= 4 * kWave ? 256 : kSelectThreads;  // <= 256 lists: one wave finds the bound
   } else if (keys_per_query <= 4096 && n_candidates <= 128 && refine.E == nullptr) {
     threads = 256;   // (refine mode re-scores its candidates one wave each: sixteen waves)
   }
-  size_t dyn = 0;
+  size_t dyn = refine_lists ? static_cast<size_t>(kMaxSortCandidates) * 8 : 0;     // scratch of the exact re-scoring
   if (d_counts != nullptr && seg.lds_keys > 0) {
     dyn = static_cast<size_t>(seg.lds_keys) * 8;
     static PerDeviceOnce attr_once;

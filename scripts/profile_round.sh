@@ -47,6 +47,7 @@ trace c2 --steps 300 --warmup 30
 trace c3 --config c3 --steps 40 --warmup 5
 trace c5 --config c5 --steps 20 --warmup 3
 trace c2b256 --batch 256 --steps 60 --warmup 10
+trace c2b1s --batch 1 --shadow 1 --steps 300 --warmup 30
 pmc FETCH_SIZE_c2 FETCH_SIZE --steps 40 --warmup 5
 pmc WRITE_SIZE_c2 WRITE_SIZE --steps 40 --warmup 5
 pmc FETCH_SIZE_c3 FETCH_SIZE --config c3 --steps 10 --warmup 2
@@ -55,6 +56,7 @@ pmc SQ_LDS_c3 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYC
 pmc SQ_MFMA_c3 "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_COEXEC_CYCLES" --config c3 --steps 10 --warmup 2
 pmc SQ_WAIT_c3 "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" --config c3 --steps 10 --warmup 2
 pmc FETCH_SIZE_c5 FETCH_SIZE --config c5 --steps 10 --warmup 2
+pmc FETCH_SIZE_c2b1s FETCH_SIZE --batch 1 --shadow 1 --steps 40 --warmup 5
 pmc WRITE_SIZE_c5 WRITE_SIZE --config c5 --steps 10 --warmup 2
 probe_trace f32b32 32
 probe_trace bf16b32 --bf16 32
@@ -69,5 +71,6 @@ probe_pmc SQ_WAIT_f32b32 "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INS
 probe_pmc WRITE_SIZE_bf16b32 WRITE_SIZE --bf16 32
 python3 scripts/summarize_pmc.py $OUT --commit $COMMIT --record "1000000x768x4xB1=scan_rows_f32" "1000000x768x2xB256=mfma_scan_bf16_s16<48, false>" \
   "1000000x768x4xB32=mfma_scan_f32<false, 3, false, false>" "1000000x768x2xB32=mfma_scan_f32<true, 3, false, false>" \
+  "1000000x768x2xB1=scan_rows_bf16<3, 1, 0, 1, true>" \
   "rowcos_1000000x512=row_cosine_512_kernel<2>" "fit_med_7x1000000=fit_fast_kernel<false>" "fit_mad_7x1000000=fit_fast_kernel<true>" > $OUT/pmc_summary.txt
 cat $OUT/pmc_summary.txt

@@ -481,9 +481,10 @@ def test_fp32_corpus_with_bf16_shadow_equals_the_one_query_search(dim, n, b, k):
     assert np.array_equal(ids2, ids) and np.array_equal(sc2, sc)
 
 
-@pytest.mark.parametrize("dim,n,k", [(768, 70_000, 10), (256, 131_073, 128), (512, 66_000, 1)])
+@pytest.mark.parametrize("dim,n,k", [(768, 70_000, 10), (256, 131_073, 128), (512, 66_000, 1), (768, 80_001, 16), (256, 70_000, 17)])
 def test_one_query_through_the_bf16_shadow_equals_the_fp32_row_scan(dim, n, k):
-    """enable_bf16_shadow(single_query=True): ONE query runs the depth-split pass over the shadow + the exact re-scoring;
+    """enable_bf16_shadow(single_query=True): ONE query runs a pass over the shadow — cuts of up to 32 rows (k <= 16) the bf16 row
+    kernel with per-workgroup lists long enough for the error band, larger cuts the depth-split pass — + the exact re-scoring;
     ids and scores equal the plain fp32 one-query search bit for bit, for many queries (incl. an exact copy of a row),
     through the blocking API and on device tensors; without the switch one query keeps the fp32 row scan."""
     import torch
