@@ -122,7 +122,8 @@ int dewi_knn_rerank_f32(const float* d_E, int64_t n_rows, int dim, const float* 
 /* The same search over an fp32 corpus that also has a bf16 SHADOW copy (d_E_bf16: the stored rows rounded with
  * dewi_convert_f32_to_bf16; +50 % memory): a matrix-core pass runs over the shadow — more than 32 queries: the 256-query
  * pass (half the bytes, 256 queries per corpus pass instead of 32); 1-32 queries: the depth-split pass in its bf16
- * geometry (half the bytes; c = min(2k, n_rows) <= 256) — as a PRE-SELECTION: its scores are within a
+ * geometry (half the bytes; c = min(2k, n_rows) <= 256); ONE query with c <= 32: the bf16 row kernel with per-workgroup
+ * lists long enough for the error band (two launches) — as a PRE-SELECTION: its scores are within a
  * proven bound of the fp32 ones (bf16 rounding of unit vectors: 2^-8 plus accumulation), the candidate cut is widened by
  * that bound — and the candidates are re-scored from the fp32 rows with the row kernels' arithmetic, so ids and scores
  * equal dewi_knn_rerank_f32's one-query results bit for bit.  The bound assumes STORED rows of norm <= 1.0001 (what

@@ -21,3 +21,21 @@ print("search_device enqueue     %.1f us" % med(lambda j: c.search_device(qd, 10
 hp = torch.empty((1, 10), dtype=torch.int64, pin_memory=True)
 print("d2h 80 B pinned + sync    %.1f us" % med(lambda j: (hp.copy_(oi, non_blocking=True), torch.cuda.current_stream().synchronize())))
 print("empty sync                %.1f us" % med(lambda j: torch.cuda.current_stream().synchronize()))
+# zero-copy results: the select kernel writes ids / scores straight into pinned host memory (device-visible under unified addressing)
+import ctypes
+from dewi import _native as nat
+hb = torch.empty(1 * 10 * 12, dtype=torch.uint8, pin_memory=True)
+h_ids = hb[:80].view(torch.int64).view(1, 10); h_sc = hb[80:].view(torch.float32).view(1, 10)
+lib = nat.load_library()
+ws = c._workspace(1, 20)
+def zc(j):
+    rc = lib.dewi_knn_rerank_f32(nat.ptr(c.emb), c.n_rows, c.dim, nat.ptr(qd), 1, nat.ptr(c.dewi32), nat.ptr(c.ent32), 10, 0.3, 0.0, 0,
+                                 h_ids.data_ptr(), h_sc.data_ptr(), nat.ptr(ws), ws.numel(), nat.stream_ptr())
+    assert rc == 0
+    torch.cuda.current_stream().synchronize()
+print("search (pinned outputs) + sync %.1f us" % med(zc))
+c.search_device(qd, 10, 0.3, 0.0, oi, os_); torch.cuda.synchronize()
+print("zero-copy result equal:", bool((h_ids == oi.cpu()).all()) and bool((h_sc == os_.cpu()).all()))
+def plain(j):
+    c.search_device(qd, 10, 0.3, 0.0, oi, os_); hp.copy_(oi, non_blocking=True); torch.cuda.current_stream().synchronize()
+print("search_device + d2h + sync     %.1f us" % med(plain))
