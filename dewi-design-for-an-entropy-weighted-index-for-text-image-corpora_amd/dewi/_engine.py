@@ -106,8 +106,9 @@ class DeviceCorpus:
         (``dewi_knn_rerank_f32_shadow``): results equal the one-query search bit for bit.  dim 256 / 512 / 768, >= 64 K
         rows; any other shape simply takes the usual path.
 
-        ``single_query=True`` sends one-query searches through the shadow as well (same pass, same re-scoring, same
-        answers: 0.26 ms instead of 0.43 at 1 M x 768).  Off by default: ``search_device`` with one query is then no
+        ``single_query=True`` sends one-query searches through the shadow as well (k <= 16: the bf16 row kernel with
+        per-workgroup lists long enough for the error band, 0.24 ms instead of 0.43 at 1 M x 768; larger k: the pass with one
+        active query, 0.26 ms; same re-scoring, same answers).  Off by default: ``search_device`` with one query is then no
         longer "always answered" — like any matrix-core batch it may come back refused (id -1) on adversarial corpora;
         the blocking ``search`` and ``PipelinedSearcher.drain`` repair such a query on the plain fp32 scan."""
         torch = _torch()
