@@ -631,7 +631,49 @@ def run_c2(args, torch, dist, eng, nat, rank, world, device):
             raise SystemExit("parity gate failed: the bench result is invalid")
         # C1 (configs[0]) through the full add / build / search API, GPU and CPU oracle side by side
         result["c1_api"] = c1_api_leg(orc, threads)
+    # ------------------------------------------------------------------ informational: the same queries through the opt-in bf16 shadow
+    # NOT part of `value` (the timed region above is the plain fp32 scan over N*d*4 bytes): the one-query search of a corpus
+    # that also keeps a bf16 copy (+50 % memory) — pre-selection over the copy, candidates re-scored from the fp32 rows, answers
+    # checked here to be the fp32 scan's bit for bit (its own line: --batch 1 --shadow 1).
+    if (rank == 0 and world == 1 and not sharded and B == 1 and not shadowed and args.shadow < 0 and args.dim in (256, 512, 768)
+            and c <= 256 and n_local >= 64 * 1024):
+        result["opt_in_bf16_shadow"] = shadow_leg(torch, corpus, Q, k, eta, min(64, n_distinct))
     return result
+
+
+def shadow_leg(torch, corpus, Q, k, eta, n_check):
+    try:
+        dev = corpus.device
+        want_ids = torch.empty((n_check, 1, k), dtype=torch.int64, device=dev)
+        want_sc = torch.empty((n_check, 1, k), dtype=torch.float32, device=dev)
+        got_ids, got_sc = torch.empty_like(want_ids), torch.empty_like(want_sc)
+        for j in range(n_check):
+            corpus.search_device(Q[j], k, eta, 0.0, want_ids[j], want_sc[j])
+        corpus.enable_bf16_shadow(single_query=True)
+        for j in range(n_check):
+            corpus.search_device(Q[j], k, eta, 0.0, got_ids[j], got_sc[j])
+        torch.cuda.synchronize()
+        refused = int((got_ids[:, 0, 0] < 0).sum())
+        ok = got_ids[:, 0, 0] >= 0
+        equal = bool(torch.equal(got_ids[ok], want_ids[ok]) and torch.equal(got_sc[ok], want_sc[ok]))
+        steps, n_q = 500, int(Q.shape[0])
+        for i in range(50):
+            corpus.search_device(Q[i % n_q], k, eta, 0.0, got_ids[i % n_check], got_sc[i % n_check])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            corpus.search_device(Q[i % n_q], k, eta, 0.0, got_ids[i % n_check], got_sc[i % n_check])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return {"queries_per_s": round(steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 5), "steps": steps,
+                "answers_bit_equal_to_the_fp32_scan": equal, "queries_compared": int(ok.sum()), "refused": refused,
+                "extra_hbm_bytes": int(corpus.shadow.numel() * 2),
+                "note": "informational, not `value`: enable_bf16_shadow(single_query=True) — bf16 copy pre-selects, fp32 rows re-score"}
+    except Exception as e:  # noqa: BLE001  (an extra leg must never cost the headline line)
+        return {"error": repr(e)[:300]}
+    finally:
+        corpus.shadow = None
+        corpus.shadow_min_batch = 2
 
 
 def c1_api_leg(orc, threads):
