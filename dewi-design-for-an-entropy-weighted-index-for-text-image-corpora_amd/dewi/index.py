@@ -42,7 +42,8 @@ class DewiIndex(BaseIndex):
         if self._use_ann and backend is not IndexBackend.EXACT:
             # index.py:58-60: requested ANN library missing -> warn, use the exact index
             logger.warning("ANN backend unavailable; falling back to ExactIndex.")
-        exact_kwargs = {k: v for k, v in kwargs.items() if k in ("device",)}
+        # (additive switches of the exact backend; everything else in **kwargs is accepted and ignored as in the reference)
+        exact_kwargs = {k: v for k, v in kwargs.items() if k in ("device", "batch_shadow", "shadow_single_query")}
         self._backend: BaseIndex = ExactIndex(dim, space, **exact_kwargs)
 
     # ------------------------------------------------------------------ ingest / build

@@ -560,6 +560,14 @@ def test_exact_index_with_batch_shadow_answers_as_the_plain_index():
             ref = plain.search(Q[j], k=k, eta=0.3, entropy_pref=0.1)
             assert [r[0] for r in got] == [r[0] for r in ref] and [r[1] for r in got] == [r[1] for r in ref]
             assert [r[0] for r in got] == [ids[r] for r in want_rows[j]]
+    from dewi.index import DewiIndex
+    fac = DewiIndex(dim=dim, space="cosine", use_ann=False, rerank_eta=0.3, entropy_pref=0.1, batch_shadow=True, shadow_single_query=True)
+    fac.add_batch_columns(ids, raw, cols)
+    fac.build()
+    assert fac._backend._corpus.shadow is not None and fac._backend._corpus.shadow_min_batch == 1
+    got = fac.search(Q[3], k=k)
+    ref = plain.search(Q[3], k=k, eta=0.3, entropy_pref=0.1)
+    assert [r[0] for r in got] == [r[0] for r in ref] and [r[1] for r in got] == [r[1] for r in ref]
     l2 = ExactIndex(dim=dim, space="l2", batch_shadow=True)          # the switch is a no-op outside cosine
     l2.add_batch_columns(ids[:1000], raw[:1000], {kk: np.asarray(v)[:1000] for kk, v in cols.items()})
     l2.build()
