@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Randomised check of the one-query search through the bf16 shadow (GPU box; not part of the suite):
+    python3 scripts/fuzz_shadow_single.py [--seconds 200] [--seed 1]
+Random fp32 cosine corpora (64 K - 250 K rows, dim 256 / 512 / 768; some with blocks of near-duplicate rows), per corpus 40
+random (query, k, eta, entropy_pref) draws — queries are gaussian, copies of rows, or rows plus small noise.  Every answer of
+``enable_bf16_shadow(single_query=True)`` must equal the plain fp32 one-query search BIT FOR BIT (ids and scores); a raw
+device call may come back refused (id -1), the blocking search never."""
+import argparse
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent.parent
+for p in (REPO / "dewi-design-for-an-entropy-weighted-index-for-text-image-corpora_amd", REPO / "oracle", REPO / "tests"):
+    sys.path.insert(0, str(p))
+import torch  # noqa: E402
+
+import dewi_oracle as orc  # noqa: E402
+from dewi import _engine as eng  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=200.0)
+ap.add_argument("--seed", type=int, default=1)
+args = ap.parse_args()
+rs = np.random.RandomState(args.seed)
+t_end = time.time() + args.seconds
+n_corp = n_q = n_refused = n_rows_route = 0
+fails = []
+while time.time() < t_end:
+    dim = int(rs.choice([256, 512, 768]))
+    n = int(rs.randint(65_536, 250_000))
+    raw = orc.synth_corpus(n, dim, seed=int(rs.randint(1 << 30)))
+    dup = rs.rand() < 0.4
+    if dup:                                   # a block of near-copies of one row: many rows inside the error band
+        m = int(rs.choice([30, 300, 3000]))
+        at = int(rs.randint(0, n - m))
+        raw[at:at + m] = raw[7] + rs.randn(m, dim).astype(np.float32) * float(rs.choice([0.0, 1e-4, 1e-2]))
+    cols = orc.synth_payload_columns(n, seed=int(rs.randint(1 << 30)))
+    plain = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    sh = eng.DeviceCorpus(plain.emb, plain.dewi32, plain.ent32, "cosine").enable_bf16_shadow(single_query=True)
+    n_corp += 1
+    for _ in range(40):
+        kind = rs.randint(4)
+        q = rs.randn(dim).astype(np.float32)
+        if kind == 1:
+            q = raw[int(rs.randint(n))] * float(rs.uniform(0.1, 9.0))
+        elif kind == 2:
+            q = raw[7 if dup else int(rs.randint(n))] + rs.randn(dim).astype(np.float32) * 0.05
+        k = int(rs.choice([1, 2, 5, 10, 16, 17, 40, 128]))
+        eta = float(rs.choice([0.0, 0.3, 0.7, 1.0]))
+        pref = float(rs.choice([0.0, 0.2, -0.5]))
+        n_rows_route += k <= 16
+        raw_ids, _ = sh.search_device(torch.from_numpy(q[None]).cuda(), k, eta, pref)
+        n_refused += int(raw_ids[0, 0] < 0)
+        ids, sc = sh.search(q, k, eta, pref)
+        i1, s1 = plain.search(q, k, eta, pref)
+        n_q += 1
+        if not (np.array_equal(ids, i1) and np.array_equal(sc, s1) and ids.min() >= 0):
+            case = dict(dim=dim, n=n, dup=dup, kind=int(kind), k=k, eta=eta, pref=pref)
+            fails.append(case)
+            print("FAIL", case, ids[0, :5], i1[0, :5], flush=True)
+    print(f"[{args.seconds - (t_end - time.time()):5.0f} s] {n_corp} corpora, {n_q} queries ({n_rows_route} on the row-kernel route), "
+          f"{n_refused} raw calls refused and repaired, {len(fails)} failures", flush=True)
+print(f"DONE: {n_corp} corpora, {n_q} queries, {n_refused} refused and repaired, {len(fails)} failures")
+sys.exit(1 if fails else 0)
