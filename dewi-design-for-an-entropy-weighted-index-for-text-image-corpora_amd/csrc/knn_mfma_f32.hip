@@ -158,8 +158,8 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
                                                                 const float* __restrict__ qn2, float aux) {
   // aux: l2 — the error bound per unit of ||e||^2 + ||q||^2 (exact-refine mode, 0 = unrefined); cosine — a bias subtracted
   // from every threshold (0, or two error bounds when the pass pre-selects over the bf16 shadow of an fp32 corpus)
-  const float l2_margin = L2 ? aux : 0.f;
 #if defined(__HIP_DEVICE_COMPILE__)
+  const float l2_margin = L2 ? aux : 0.f;
   using G = DepthGeo<BF16>;
   constexpr int DIM = CH * kF32ChunkCols;
   constexpr int RM = G::kRing - 1;                             // ring slot of chunk g: g & RM
