@@ -335,7 +335,7 @@ __device__ __forceinline__ int refine_rescore(uint64_t* keys, int n_candidates, 
   if (n_cand > kMaxSortCandidates) return -2;
   // exact scores, one wave per candidate, kBatch candidates per wave and round with all their loads in flight together
   // (the candidates of a query are a few dozen to a few hundred 3 KiB rows: latency, not bandwidth)
-  constexpr int kMaxUnits = 3, kBatch = 4;         // l2 over an fp32 corpus on the matrix cores: dim 256 / 512 / 768
+  constexpr int kMaxUnits = 4, kBatch = 4;         // l2 over an fp32 corpus on the matrix cores: dim 256 / 512 / 768; bf16 shadow: also 1024
   const int units = rf.dim >> 8;                   // U = dim / 256 sixteen-byte units per lane
   typedef float f32x4r __attribute__((ext_vector_type(4)));
   const f32x4r* qp = reinterpret_cast<const f32x4r*>(rf.Q + static_cast<int64_t>(q) * rf.dim) + lane;
