@@ -277,7 +277,7 @@ def run_c2(args, torch, dist, eng, nat, rank, world, device):
     n_q = args.warmup + args.steps
     B = args.batch
     # (the headline line — no flags, one query per step — never takes the shadow: it stays the plain fp32 scan over N*d*4 bytes)
-    shadowed = (B > 32 if args.shadow < 0 else args.shadow == 1) and world == 1 and args.dim in (256, 512, 768, 1024) and \
+    shadowed = (B > 32 if args.shadow < 0 else args.shadow == 1) and world == 1 and args.dim in (256, 512, 768, 1024, 1536) and \
         min(2 * args.k, total_rows) <= (512 if B > 32 else 256)
     if shadowed:
         # query batches over the fp32 corpus: a matrix-core pass over a bf16 shadow copy as a pre-selection, candidates
@@ -635,7 +635,7 @@ def run_c2(args, torch, dist, eng, nat, rank, world, device):
     # NOT part of `value` (the timed region above is the plain fp32 scan over N*d*4 bytes): the one-query search of a corpus
     # that also keeps a bf16 copy (+50 % memory) — pre-selection over the copy, candidates re-scored from the fp32 rows, answers
     # checked here to be the fp32 scan's bit for bit (its own line: --batch 1 --shadow 1).
-    if (rank == 0 and world == 1 and not sharded and B == 1 and not shadowed and args.shadow < 0 and args.dim in (256, 512, 768, 1024)
+    if (rank == 0 and world == 1 and not sharded and B == 1 and not shadowed and args.shadow < 0 and args.dim in (256, 512, 768, 1024, 1536)
             and c <= 256 and n_local >= 64 * 1024):
         result["opt_in_bf16_shadow"] = shadow_leg(torch, corpus, Q, k, eta, min(64, n_distinct))
     return result

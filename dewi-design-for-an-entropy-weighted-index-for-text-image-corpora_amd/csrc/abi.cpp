@@ -468,11 +468,12 @@ int dewi_knn_rerank_f32_shadow(const float* d_E, const uint16_t* d_E_bf16, int64
   if (rc) return rc;
   const int64_t c64 = (2ll * k < n_rows) ? 2ll * k : n_rows;
   // the shadow pre-selects only where a matrix-core pass runs over it and the one-query search of the same corpus takes the
-  // row-per-wave kernel whose arithmetic the refinement repeats (dim 256 / 512 / 768 / 1024: scan_rows_f32<U = dim / 256>, four
-  // 16-byte units per lane at most in the re-scoring); everything else is the plain search.  dim 1024 has no 256-query pass:
+  // row-per-wave kernel whose arithmetic the refinement repeats (dim 256 / 512 / 768 / 1024 / 1536: scan_rows_f32<U = dim / 256>, up to six
+  // 16-byte units per lane in the re-scoring); everything else is the plain search.  dim 1024 / 1536 have no 256-query pass
+  // (and 1536 no bf16 row kernel: one query takes the depth-split pass too):
   // its batches run the depth-split pass over the shadow in groups of 32 (2 GB instead of 4 GB per group at 1 M rows)
   const bool usable = d_E_bf16 != nullptr && g_tuning.mfma != 0 && space == DEWI_SPACE_COSINE && k > 0 && k <= n_rows &&
-                      (dim == 256 || dim == 512 || dim == 768 || dim == 1024);
+                      (dim == 256 || dim == 512 || dim == 768 || dim == 1024 || dim == 1536);
   const bool use_big = usable && n_queries > 32 && c64 <= 512 &&
                        dewi::mfma_path_supported(n_rows, dim, n_queries, static_cast<int>(c64), space);
   // (a SINGLE query takes the depth-split pass too: one pass over half the bytes + the exact re-scoring, 0.26 ms instead of

@@ -327,7 +327,8 @@ __device__ __forceinline__ int refine_from_sorted_lists(const uint64_t* __restri
 }
 
 // Part 2: sh.count candidates in sh.sel2 -> exact scores -> the best n_candidates, sorted, in sh.sel.
-__device__ __forceinline__ int refine_rescore(uint64_t* keys, int n_candidates, SelectShared& sh, const RefineParams& rf, int q) {
+template <int kMaxUnits, int kBatch>
+__device__ __forceinline__ int refine_rescore_units(uint64_t* keys, int n_candidates, SelectShared& sh, const RefineParams& rf, int q) {
   const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
   const int lane = tid & 63, wave = tid >> 6, n_waves = nt >> 6;
   const bool l2 = rf.space == DEWI_SPACE_L2;
@@ -335,7 +336,8 @@ __device__ __forceinline__ int refine_rescore(uint64_t* keys, int n_candidates, 
   if (n_cand > kMaxSortCandidates) return -2;
   // exact scores, one wave per candidate, kBatch candidates per wave and round with all their loads in flight together
   // (the candidates of a query are a few dozen to a few hundred 3 KiB rows: latency, not bandwidth)
-  constexpr int kMaxUnits = 4, kBatch = 4;         // l2 over an fp32 corpus on the matrix cores: dim 256 / 512 / 768; bf16 shadow: also 1024
+  // <4, 4>: l2 over an fp32 corpus on the matrix cores (dim 256 / 512 / 768) and the bf16 shadow up to dim 1024; <6, 2>: the shadow at
+  // dim 1536 (six units per lane: two candidates per wave and round keep the row fragments inside the register budget)
   const int units = rf.dim >> 8;                   // U = dim / 256 sixteen-byte units per lane
   typedef float f32x4r __attribute__((ext_vector_type(4)));
   const f32x4r* qp = reinterpret_cast<const f32x4r*>(rf.Q + static_cast<int64_t>(q) * rf.dim) + lane;
@@ -403,6 +405,10 @@ __device__ __forceinline__ int refine_rescore(uint64_t* keys, int n_candidates, 
     bitonic_sort_desc<false>(sh.sel, nullptr, p2);
   }
   return n_cand < n_candidates ? n_cand : n_candidates;
+}
+__device__ __forceinline__ int refine_rescore(uint64_t* keys, int n_candidates, SelectShared& sh, const RefineParams& rf, int q) {
+  if (rf.dim > 1024) return refine_rescore_units<6, 2>(keys, n_candidates, sh, rf, q);
+  return refine_rescore_units<4, 4>(keys, n_candidates, sh, rf, q);
 }
 
 // Gathers the best n_candidates keys of one query into sh.sel, sorted descending; returns how many

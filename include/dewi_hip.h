@@ -127,7 +127,7 @@ int dewi_knn_rerank_f32(const float* d_E, int64_t n_rows, int dim, const float* 
  * proven bound of the fp32 ones (bf16 rounding of unit vectors: 2^-8 plus accumulation), the candidate cut is widened by
  * that bound — and the candidates are re-scored from the fp32 rows with the row kernels' arithmetic, so ids and scores
  * equal dewi_knn_rerank_f32's one-query results bit for bit.  The bound assumes STORED rows of norm <= 1.0001 (what
- * dewi_normalize_rows_f32 leaves; the host layer checks it once).  Cosine, dim 256 / 512 / 768 / 1024, corpus >= 64 K rows;
+ * dewi_normalize_rows_f32 leaves; the host layer checks it once).  Cosine, dim 256 / 512 / 768 / 1024 / 1536, corpus >= 64 K rows;
  * any other call (and d_E_bf16 == NULL) behaves exactly as dewi_knn_rerank_f32.  A query with more candidates inside
  * the error band than the sort holds comes back refused (id -1) like any matrix-core batch.  (ABI 4.) */
 int dewi_knn_rerank_f32_shadow(const float* d_E, const uint16_t* d_E_bf16, int64_t n_rows, int dim, const float* d_Q,

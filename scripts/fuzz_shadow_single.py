@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised check of the one-query search through the bf16 shadow (GPU box; not part of the suite):
     python3 scripts/fuzz_shadow_single.py [--seconds 200] [--seed 1]
-Random fp32 cosine corpora (64 K - 250 K rows, dim 256 / 512 / 768 / 1024; some with blocks of near-duplicate rows), per corpus 40
+Random fp32 cosine corpora (64 K - 250 K rows, dim 256 / 512 / 768 / 1024 / 1536; some with blocks of near-duplicate rows), per corpus 40
 random (query, k, eta, entropy_pref) draws — queries are gaussian, copies of rows, or rows plus small noise.  Every answer of
 ``enable_bf16_shadow(single_query=True)`` must equal the plain fp32 one-query search BIT FOR BIT (ids and scores); a raw
 device call may come back refused (id -1), the blocking search never."""
@@ -29,7 +29,7 @@ t_end = time.time() + args.seconds
 n_corp = n_q = n_refused = n_rows_route = 0
 fails = []
 while time.time() < t_end:
-    dim = int(rs.choice([256, 512, 768, 1024]))
+    dim = int(rs.choice([256, 512, 768, 1024, 1536]))
     n = int(rs.randint(65_536, 250_000))
     raw = orc.synth_corpus(n, dim, seed=int(rs.randint(1 << 30)))
     dup = rs.rand() < 0.4

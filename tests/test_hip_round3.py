@@ -451,7 +451,8 @@ def test_bf16_dim768_shards_are_bit_equal_on_even_boundaries():
 @pytest.mark.parametrize("dim,n,b,k", [(768, 70_000, 256, 10), (768, 100_003, 300, 100), (256, 131_072, 64, 50), (512, 66_000, 33, 1),
                                        (768, 80_000, 32, 10), (512, 70_000, 2, 5), (256, 66_000, 8, 128), (768, 66_001, 5, 100),
                                        (768, 120_526, 65, 129),    # (the pre-selection's own workspace size, a fuzz find)
-                                       (1024, 70_000, 40, 10), (1024, 66_000, 8, 50)])   # dim 1024: depth-split pass in groups of 32
+                                       (1024, 70_000, 40, 10), (1024, 66_000, 8, 50),    # dim 1024 / 1536: depth-split pass in groups of 32
+                                       (1536, 66_000, 33, 10), (1536, 70_001, 4, 100)])
 def test_fp32_corpus_with_bf16_shadow_equals_the_one_query_search(dim, n, b, k):
     """fp32 corpus + bf16 shadow (dewi_knn_rerank_f32_shadow): a batch of cosine queries runs a matrix-core pass over the
     shadow as a pre-selection (2-32 queries: the depth-split pass in its bf16 geometry; more: the 256-query pass) and
@@ -483,7 +484,7 @@ def test_fp32_corpus_with_bf16_shadow_equals_the_one_query_search(dim, n, b, k):
 
 
 @pytest.mark.parametrize("dim,n,k", [(768, 70_000, 10), (256, 131_073, 128), (512, 66_000, 1), (768, 80_001, 16), (256, 70_000, 17),
-                                     (1024, 70_000, 10), (1024, 66_000, 64)])
+                                     (1024, 70_000, 10), (1024, 66_000, 64), (1536, 70_000, 10)])
 def test_one_query_through_the_bf16_shadow_equals_the_fp32_row_scan(dim, n, k):
     """enable_bf16_shadow(single_query=True): ONE query runs a pass over the shadow — cuts of up to 32 rows (k <= 16) the bf16 row
     kernel with per-workgroup lists long enough for the error band, larger cuts the depth-split pass — + the exact re-scoring;
