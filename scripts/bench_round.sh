@@ -21,5 +21,10 @@ run c2_batch8_shadow --batch 8 --shadow 1 --steps 400 --warmup 100
 run c2_batch1_shadow --batch 1 --shadow 1
 run c2_batch256_shadow --batch 256 --steps 400 --warmup 100
 run c2_batch256_shadow_k100 --batch 256 --k 100 --steps 400 --warmup 100
+# other embedding widths (not BASELINE configs): the one-query search, plain and through the opt-in shadow
+run dim1024 --dim 1024 --cpu-queries 0
+run dim1024_batch1_shadow --dim 1024 --batch 1 --shadow 1 --cpu-queries 0
+run dim1536 --dim 1536 --cpu-queries 0
+run dim1536_batch1_shadow --dim 1536 --batch 1 --shadow 1 --cpu-queries 0
 DEWI_BENCH_FORCE_DIST=1 python3 bench.py --docs 125000 --steps 400 --warmup 40 --cpu-queries 0 > $OUT/bench_rccl_world1_125k.json 2> $OUT/bench_rccl_world1_125k.err
 cut -c1-200 $OUT/bench_rccl_world1_125k.json
