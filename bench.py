@@ -444,7 +444,7 @@ def run_c2(args, torch, dist, eng, nat, rank, world, device):
     # --batch 1 --shadow 1 (cut of at most 32 rows): the bf16 ROW kernel over the shadow
     kernel = ("scan_rows_f32" if (B < 5 and not shadowed) else f"mfma_scan_f32<false,{args.dim // 256},false,false>" if not shadowed
               else f"mfma_scan_bf16_s16<{args.dim // 16},false>" if B > 32
-              else f"scan_rows_bf16<{args.dim // 256},1,0,1,true>" if (B == 1 and c <= 32)
+              else f"scan_rows_bf16<{args.dim // 256},1,0,1,true>" if (B == 1 and c <= 32 and args.dim <= 1024)   # (no bf16 row kernel at 1536)
               else f"mfma_scan_f32<true,{args.dim // 256},false,false>")
     traffic, traffic_note = recorded_traffic(f"{n_local}x{args.dim}x{elem}xB{B}", kernel)
     if traffic is None and shadowed and B < 32 and kernel.startswith("mfma_scan_f32"):
