@@ -9,7 +9,8 @@ import json
 import sys
 from pathlib import Path
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+args_ = [a for a in sys.argv[1:] if not a.startswith("--")]
+tag = args_[0] if args_ else "r03"
 root = Path(__file__).resolve().parent.parent / "profiles" / tag
 out = ["<!-- generated:begin (scripts/profiles_table.py) -->", "",
        "| bench line | value | ms / step | dominant kernel | mean kernel ms | frac of peak | traffic MB (PMC) | p50 ms (API) | CPU oracle |",
@@ -43,6 +44,10 @@ for f in sorted(glob.glob(str(root / "kernel_stats_*.csv"))):
 out += ["", "<!-- generated:end -->"]
 readme = root / "README.md"
 text = readme.read_text()
+if "--check" in sys.argv:      # exit 1 when the README's block is not what the committed files say (tests/test_cpu_host_logic.py)
+    have = text[text.index("<!-- generated:begin"): text.index("<!-- generated:end -->") + len("<!-- generated:end -->")] \
+        if "<!-- generated:begin" in text else ""
+    sys.exit(0 if have == "\n".join(out) else 1)
 b, e = "<!-- generated:begin", "<!-- generated:end -->"
 block = "\n".join(out)
 if b in text:

@@ -251,3 +251,14 @@ def test_bench_plain_gpus_n_reaches_the_launcher():
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     tail = cmd[cmd.index(str(repo / "bench.py")) + 1:]
     assert tail == ["--gpus", "4", "--steps", "7", "--warmup", "3"]          # the same command line reaches every rank
+
+
+def test_profiles_readme_block_matches_the_committed_files():
+    """profiles/r03/README.md ends with a block generated from bench_*.json / kernel_stats_*.csv (scripts/profiles_table.py):
+    it must be what those files say now."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parent.parent
+    rc = subprocess.run([sys.executable, str(repo / "scripts" / "profiles_table.py"), "r03", "--check"], cwd=repo).returncode
+    assert rc == 0, "profiles/r03/README.md: run `python scripts/profiles_table.py r03`"
