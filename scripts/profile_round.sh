@@ -48,6 +48,7 @@ trace c3 --config c3 --steps 40 --warmup 5
 trace c5 --config c5 --steps 20 --warmup 3
 trace c2b256 --batch 256 --steps 60 --warmup 10
 trace c2b1s --batch 1 --shadow 1 --steps 300 --warmup 30
+trace c2b32s --batch 32 --shadow 1 --steps 100 --warmup 20
 pmc FETCH_SIZE_c2 FETCH_SIZE --steps 40 --warmup 5
 pmc WRITE_SIZE_c2 WRITE_SIZE --steps 40 --warmup 5
 pmc FETCH_SIZE_c3 FETCH_SIZE --config c3 --steps 10 --warmup 2
