@@ -163,7 +163,7 @@ int run_scan(const KnnLayout& L, const void* d_E, int elem_type, int64_t n_rows,
   uint64_t* keys = reinterpret_cast<uint64_t*>(ws + L.keys_off);
   float* qn = reinterpret_cast<float*>(ws + L.qn_off);
   hipError_t e;
-  if (!L.plan.fast) {
+  if (!L.plan.raw_queries) {
     e = dewi::launch_prepare_queries(d_Q, qn, n_queries, dim, space, elem_type ? 1 : 0, stream);
     if (e != hipSuccess) return hip_fail(e, "prepare_queries");
   }
@@ -173,12 +173,12 @@ int run_scan(const KnnLayout& L, const void* d_E, int elem_type, int64_t n_rows,
     // queries per corpus pass: 8 (fp32 row-per-wave kernel with one sorted list per workgroup), else 4, else 1
     static const bool nq8_enabled = [] { const char* e = getenv("DEWI_SCAN_NQ8"); return e == nullptr || atoi(e) != 0; }();
     const bool can8 = !elem_type && L.plan.fast && L.plan.slots == 1 && nq8_enabled;
-    const int nq = (can8 && n_queries - q >= 8) ? 8 : ((n_queries - q >= 4) ? 4 : 1);
+    const int nq = (can8 && n_queries - q >= 8) ? 8 : ((n_queries - q >= L.plan.nq_max) ? L.plan.nq_max : 1);
     if (elem_type)
-      e = dewi::launch_scan_bf16(L.plan, static_cast<const uint16_t*>(d_E), n_rows, dim, d_Q, L.plan.fast ? nullptr : qn,
+      e = dewi::launch_scan_bf16(L.plan, static_cast<const uint16_t*>(d_E), n_rows, dim, d_Q, L.plan.raw_queries ? nullptr : qn,
                                  q, nq, n_candidates, space, keys, stream);
     else
-      e = dewi::launch_scan_f32(L.plan, static_cast<const float*>(d_E), n_rows, dim, d_Q, L.plan.fast ? nullptr : qn, q,
+      e = dewi::launch_scan_f32(L.plan, static_cast<const float*>(d_E), n_rows, dim, d_Q, L.plan.raw_queries ? nullptr : qn, q,
                                 nq, n_candidates, space, keys, stream);
     if (e != hipSuccess) return hip_fail(e, "scan launch");
     q += nq;

@@ -17,26 +17,9 @@
 // span of the matrix.  Query fragments live in registers for the whole kernel (the same 4*U
 // floats per lane are needed for every row), so there is no LDS traffic at all; the cross-lane
 // sum runs on the DPP crossbar.
-#include "scan_common.hpp"
+#include "scan_any.hpp"
 
 namespace dewi {
-
-template <int SPACE>
-__device__ __forceinline__ float accum4(f32x4 e, f32x4 q, float acc) {
-  if constexpr (SPACE == DEWI_SPACE_COSINE) {
-    acc = __builtin_fmaf(e.x, q.x, acc);
-    acc = __builtin_fmaf(e.y, q.y, acc);
-    acc = __builtin_fmaf(e.z, q.z, acc);
-    acc = __builtin_fmaf(e.w, q.w, acc);
-  } else {
-    float d;
-    d = e.x - q.x; acc = __builtin_fmaf(d, d, acc);
-    d = e.y - q.y; acc = __builtin_fmaf(d, d, acc);
-    d = e.z - q.z; acc = __builtin_fmaf(d, d, acc);
-    d = e.w - q.w; acc = __builtin_fmaf(d, d, acc);
-  }
-  return acc;
-}
 
 // ---------------------------------------------------------------------------------------------
 // Fast path: dim == 256*U, one row per wavefront step, R rows per iteration, NQ queries per pass.
@@ -367,6 +350,31 @@ ScanPlan plan_scan(int64_t n_rows, int dim, int elem_bytes, int n_candidates, in
   const int units = (dim + p.vec - 1) / p.vec;
   p.group = p.fast ? kWave : (next_pow2(units) > kWave ? kWave : next_pow2(units));
   if (!p.fast) p.rows_per_iter = kWave / p.group;
+  p.kind = p.fast ? kScanFast : kScanGeneric;
+  p.nq_max = 4;
+  p.units = p.u_pad = p.log2p = 0;
+  // rows of whole 16-byte units outside the tuned set: the any-width kernels (scan_any.hpp), queries in registers
+  const int cols_per_unit = elem_bytes == 2 ? 8 : 4;
+  if (!p.fast && dim % cols_per_unit == 0) {
+    const int n_units = dim / cols_per_unit;
+    if (n_units <= 32) {
+      p.kind = kScanAnyShort;
+      p.units = n_units;
+      while ((1 << p.log2p) < n_units) ++p.log2p;
+      p.rows_per_iter = p.rows_per_iter_batch = (kWave >> p.log2p) * kAnyShortRows;
+    } else if (n_units <= 64 * 16) {
+      static const int pads[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
+      const int need = (n_units + 63) / 64;
+      p.kind = kScanAnyLong;
+      p.units = n_units;
+      for (int v : pads)
+        if (v >= need) { p.u_pad = v; break; }
+      if (p.u_pad > 8) p.nq_max = 2;
+      p.rows_per_iter = any_rows(p.u_pad, 1);
+      p.rows_per_iter_batch = any_rows(p.u_pad, p.nq_max);
+    }
+  }
+  p.raw_queries = p.kind != kScanGeneric;
   p.nontemporal = tuning.nontemporal < 0 ? true : tuning.nontemporal != 0;
   // One 8-wave workgroup per CU (8 waves x R*U KiB in flight each): 8 waves per CU measured
   // fastest on MI355X (1M x 768, R=8: 0.443 ms vs 0.448 ms at 32 waves per CU with R=4), and one
@@ -465,6 +473,8 @@ static hipError_t launch_scan_impl(const ScanPlan& plan, const float* E, int64_t
 hipError_t launch_scan_f32(const ScanPlan& plan, const float* d_E, int64_t n_rows, int dim, const float* d_q_raw,
                            const float* d_q_norm, int q0, int nq, int n_candidates, int space, uint64_t* d_keys,
                            hipStream_t stream) {
+  if (plan.kind == kScanAnyLong || plan.kind == kScanAnyShort)
+    return launch_scan_any_f32(plan, d_E, n_rows, dim, d_q_raw, q0, nq, n_candidates, space, d_keys, stream);
   const float* qr = d_q_raw + static_cast<int64_t>(q0) * dim;
   const float* qn = d_q_norm ? d_q_norm + static_cast<int64_t>(q0) * dim : nullptr;
   uint64_t* keys = d_keys + static_cast<int64_t>(q0) * plan.keys_per_query;

@@ -19,55 +19,6 @@
 
 namespace dewi {
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-template <bool NT>
-__device__ __forceinline__ u32x4 load_u4(const u32x4* p) {
-  if constexpr (NT) return __builtin_nontemporal_load(p);
-  return *p;
-}
-
-// fp32 -> nearest-even bf16, returned as the fp32 value it represents (NaN stays NaN).
-__device__ __forceinline__ float round_to_bf16(float f) {
-  if (f != f) return f;
-  const uint32_t u = __float_as_uint(f);
-  return __uint_as_float((u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u);
-}
-
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-
-// Cosine: 8 bf16 x bf16 products accumulated in fp32 with v_dot2c_f32_bf16 — the corpus dwords and the
-// packed query dwords are both (element 2i | element 2i+1 << 16), so no unpacking at all: 4 VALU
-// instructions per 16 bytes instead of 16 (shift, mask, 2 FMAs per dword).
-__device__ __forceinline__ float dot8_packed(u32x4 e, const uint32_t (&q)[4], float acc) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    // copy the lane to a scalar first: __builtin_bit_cast applied directly to a vector subscript
-    // (e[i]) made hipcc 7.2 use element 0 for every i
-    const uint32_t ew = e[i], qw = q[i];
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, ew), __builtin_bit_cast(bf16x2, qw), acc, false);
-  }
-  return acc;
-}
-
-template <int SPACE>
-__device__ __forceinline__ float dot8(u32x4 e, const float (&q)[8], float acc) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float lo = __uint_as_float(e[i] << 16);
-    const float hi = __uint_as_float(e[i] & 0xFFFF0000u);
-    if constexpr (SPACE == DEWI_SPACE_COSINE) {
-      acc = __builtin_fmaf(lo, q[2 * i], acc);
-      acc = __builtin_fmaf(hi, q[2 * i + 1], acc);
-    } else {
-      const float d0 = lo - q[2 * i], d1 = hi - q[2 * i + 1];
-      acc = __builtin_fmaf(d0, d0, acc);
-      acc = __builtin_fmaf(d1, d1, acc);
-    }
-  }
-  return acc;
-}
-
 template <int H, int NQ, int SPACE, int S, bool NT>
 __global__ __launch_bounds__(kScanThreads) void scan_rows_bf16(const uint16_t* __restrict__ E, int64_t n_rows,
                                                                const float* __restrict__ Q, int n_candidates,
@@ -349,6 +300,8 @@ static hipError_t launch_bf16_impl(const ScanPlan& plan, const uint16_t* E, int6
 hipError_t launch_scan_bf16(const ScanPlan& plan, const uint16_t* d_E, int64_t n_rows, int dim, const float* d_q_raw,
                             const float* d_q_norm, int q0, int nq, int n_candidates, int space, uint64_t* d_keys,
                             hipStream_t stream) {
+  if (plan.kind == kScanAnyLong || plan.kind == kScanAnyShort)
+    return launch_scan_any_bf16(plan, d_E, n_rows, dim, d_q_raw, q0, nq, n_candidates, space, d_keys, stream);
   const float* qr = d_q_raw + static_cast<int64_t>(q0) * dim;
   const float* qn = d_q_norm ? d_q_norm + static_cast<int64_t>(q0) * dim : nullptr;
   uint64_t* keys = d_keys + static_cast<int64_t>(q0) * plan.keys_per_query;

@@ -43,6 +43,10 @@ constexpr int kMaxSortCandidates = 2048;
 constexpr int kScanThreads = DEWI_SCAN_THREADS;   // 8 waves per workgroup (256 only for tuning experiments)
 constexpr int kSelectThreads = 1024;
 
+// which row kernel serves a (dim, element type): the tuned dim = 256 U kernels, the any-width kernels of scan_any.hpp
+// (rows of whole 16-byte units), or the scalar-capable generic kernel (anything else)
+enum ScanKind { kScanFast = 0, kScanAnyLong = 1, kScanAnyShort = 2, kScanGeneric = 3 };
+
 struct ScanPlan {
   int blocks;         // workgroups of kScanThreads
   int waves;          // blocks * (kScanThreads / 64)
@@ -56,6 +60,12 @@ struct ScanPlan {
   int group;          // generic path: lanes per row (power of two, <= 64)
   int vec;            // generic path: elements per 16-byte load (4 fp32 / 8 bf16) or 1 for scalar loads
   int nq_per_launch;  // queries handled by one corpus pass
+  int kind;           // ScanKind
+  int units;          // any-width kernels: 16-byte units per row
+  int u_pad;          // kScanAnyLong: units per lane the instantiated kernel holds (>= ceil(units / 64))
+  int log2p;          // kScanAnyShort: log2 of the lanes that share a row
+  int nq_max;         // most queries one corpus pass of the row kernel serves besides 1 (4; 2 for rows beyond 512 units)
+  bool raw_queries;   // the kernel normalises the raw queries itself (everything but kScanGeneric)
   int64_t keys_per_query;  // number of uint64 keys the scan emits per query
   bool nontemporal;
 };
@@ -89,6 +99,12 @@ hipError_t launch_prepare_queries_padded(const float* d_q, float* d_qn, int n_qu
 hipError_t launch_scan_f32(const ScanPlan& plan, const float* d_E, int64_t n_rows, int dim, const float* d_q_raw,
                            const float* d_q_norm, int q0, int nq, int n_candidates, int space, uint64_t* d_keys,
                            hipStream_t stream);
+
+// ---- knn_scan_any_f32.hip / knn_scan_any_bf16.hip: plan.kind == kScanAnyLong / kScanAnyShort (raw queries)
+hipError_t launch_scan_any_f32(const ScanPlan& plan, const float* d_E, int64_t n_rows, int dim, const float* d_q_raw, int q0,
+                               int nq, int n_candidates, int space, uint64_t* d_keys, hipStream_t stream);
+hipError_t launch_scan_any_bf16(const ScanPlan& plan, const uint16_t* d_E, int64_t n_rows, int dim, const float* d_q_raw, int q0,
+                                int nq, int n_candidates, int space, uint64_t* d_keys, hipStream_t stream);
 
 // ---- knn_scan_bf16.hip: the same pass over a bf16 corpus
 hipError_t launch_scan_bf16(const ScanPlan& plan, const uint16_t* d_E, int64_t n_rows, int dim, const float* d_q_raw,

@@ -16,6 +16,74 @@ __device__ __forceinline__ f32x4 load_x4(const f32x4* p) {
   return *p;
 }
 
+// ---- fp32 rows: 16-byte units of 4 columns; x y z w in this order (the exact re-scoring of select_rerank.hip repeats it) ----
+template <int SPACE>
+__device__ __forceinline__ float accum4(f32x4 e, f32x4 q, float acc) {
+  if constexpr (SPACE == DEWI_SPACE_COSINE) {
+    acc = __builtin_fmaf(e.x, q.x, acc);
+    acc = __builtin_fmaf(e.y, q.y, acc);
+    acc = __builtin_fmaf(e.z, q.z, acc);
+    acc = __builtin_fmaf(e.w, q.w, acc);
+  } else {
+    float d;
+    d = e.x - q.x; acc = __builtin_fmaf(d, d, acc);
+    d = e.y - q.y; acc = __builtin_fmaf(d, d, acc);
+    d = e.z - q.z; acc = __builtin_fmaf(d, d, acc);
+    d = e.w - q.w; acc = __builtin_fmaf(d, d, acc);
+  }
+  return acc;
+}
+
+// ---- bf16 rows: 16-byte units of 8 columns (knn_scan_bf16.hip, knn_scan_any.hpp) ----
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__device__ __forceinline__ u32x4 load_u4(const u32x4* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  return *p;
+}
+
+// fp32 -> nearest-even bf16, returned as the fp32 value it represents (NaN stays NaN).
+__device__ __forceinline__ float round_to_bf16(float f) {
+  if (f != f) return f;
+  const uint32_t u = __float_as_uint(f);
+  return __uint_as_float((u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u);
+}
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// Cosine: 8 bf16 x bf16 products accumulated in fp32 with v_dot2c_f32_bf16 — the corpus dwords and the
+// packed query dwords are both (element 2i | element 2i+1 << 16), so no unpacking at all: 4 VALU
+// instructions per 16 bytes instead of 16 (shift, mask, 2 FMAs per dword).
+__device__ __forceinline__ float dot8_packed(u32x4 e, const uint32_t (&q)[4], float acc) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    // copy the lane to a scalar first: __builtin_bit_cast applied directly to a vector subscript
+    // (e[i]) made hipcc 7.2 use element 0 for every i
+    const uint32_t ew = e[i], qw = q[i];
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, ew), __builtin_bit_cast(bf16x2, qw), acc, false);
+  }
+  return acc;
+}
+
+template <int SPACE>
+__device__ __forceinline__ float dot8(u32x4 e, const float (&q)[8], float acc) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float lo = __uint_as_float(e[i] << 16);
+    const float hi = __uint_as_float(e[i] & 0xFFFF0000u);
+    if constexpr (SPACE == DEWI_SPACE_COSINE) {
+      acc = __builtin_fmaf(lo, q[2 * i], acc);
+      acc = __builtin_fmaf(hi, q[2 * i + 1], acc);
+    } else {
+      const float d0 = lo - q[2 * i], d1 = hi - q[2 * i + 1];
+      acc = __builtin_fmaf(d0, d0, acc);
+      acc = __builtin_fmaf(d1, d1, acc);
+    }
+  }
+  return acc;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Per-wave top-c list.  Position p = slot*64 + lane is active when p < c.  `thr` is the smallest
 // active key (the entry a better candidate replaces), `thr_s` its score for the cheap test.

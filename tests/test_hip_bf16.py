@@ -32,9 +32,12 @@ def _setup(n, dim, seed):
 
 
 @pytest.mark.parametrize("dim,n", [(768, 4001), (768, 4000), (512, 3000), (256, 2501), (1024, 1501), (136, 2000),
-                                   (100, 2000), (1280, 900)])
+                                   (100, 2000), (1280, 900), (8, 3000), (64, 3000), (200, 2000), (264, 2001), (384, 2001),
+                                   (1000, 1501), (3072, 800), (5120, 502), (8192, 301), (8200, 300)])
 def test_bf16_search_vs_oracle(dim, n):
-    """Fast pair-of-rows kernel (dim = 256*H, odd and even row counts), 16-byte generic, scalar generic."""
+    """Pair-of-rows kernel (dim = 256*H, odd and even row counts); the any-width kernels (dim % 8 == 0: rows sharing a wave up
+    to 256 columns, one row per step with a predicated tail up to 8192, two queries per pass beyond 4096); scalar generic (100)
+    and the 16-byte generic beyond 8192 columns (8200)."""
     cb, Eb, dewi32, ent32 = _setup(n, dim, seed=dim + n)
     Q = orc.synth_queries(5, dim, seed=dim)
     Qp = device_prepared_queries(Q)
@@ -42,6 +45,28 @@ def test_bf16_search_vs_oracle(dim, n):
         ids, sc = cb.search(Q, k, eta, pref)
         check_batch(Eb, Qp, dewi32, ent32, k, eta, pref, "cosine", ids, sc,
                     min_decisive_frac=0.8 if k <= 10 else 0.5, **TOL)
+
+
+@pytest.mark.parametrize("dim", [64, 200, 384, 768, 1000, 3072, 5120])
+def test_bf16_l2_vs_oracle(dim):
+    """space="l2" over a bf16 corpus on the row kernels (one query and groups of 4 / 2 per pass): negated squared distance of
+    the bf16-rounded query to the bf16 rows, fp32 sums."""
+    from dewi import _engine as eng
+    n = 2000 if dim <= 1024 else 700
+    rs = np.random.RandomState(dim + 6)
+    raw = (rs.randn(n, dim) * 0.5).astype(np.float32)
+    cols = orc.synth_payload_columns(n, seed=dim)
+    cb = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"], "l2").to_bf16()
+    Eb = cb.emb.float().cpu().numpy()
+    assert np.array_equal(Eb, orc.bf16_round(raw))
+    dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    Q = (rs.randn(5, dim) * 0.5).astype(np.float32)
+    Qp = device_prepared_queries(Q, "l2")
+    # (scores of hundreds: the gap scales with them, so fewer queries are decisive at large k and wide rows — floors from
+    # the oracle alone: 5/5 at k = 10; 4-5 at k = 40; 1-4 at k = 150 up to 3072 columns, 0 at 5120)
+    for k in ((10, 40, 150) if dim <= 3072 else (10, 40)):
+        ids, sc = cb.search(Q, k, 0.3, 0.0)
+        check_batch(Eb, Qp, dewi32, ent32, k, 0.3, 0.0, "l2", ids, sc, min_decisive_frac={10: 0.8, 40: 0.6, 150: 0.2}[k], **TOL)
 
 
 def test_bf16_sharded_equals_whole():

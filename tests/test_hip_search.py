@@ -149,9 +149,13 @@ def test_g3_edge_cases(golden, golden_dir):
     assert ids.shape == (1, 0) and sc.shape == (1, 0)
 
 
-@pytest.mark.parametrize("dim", [8, 10, 16, 100, 128, 256, 260, 512, 768, 1024, 1536, 2048])
+@pytest.mark.parametrize("dim", [4, 8, 10, 12, 16, 36, 64, 100, 128, 132, 252, 256, 260, 384, 512, 768, 1000, 1024, 1280, 1536,
+                                 1792, 2048, 2304, 3072, 4096, 4100])
 def test_dimension_sweep_vs_oracle(dim):
-    """Every kernel variant: fast path (dim = 256*U), vectorised generic, scalar generic (odd dims)."""
+    """Every row-kernel variant: the tuned widths (dim = 256*U), the any-width kernels of scan_any.hpp — short rows sharing a
+    wave (dim <= 128: 1, 2, 4 ... 32 lanes per row, with idle lanes at 12 / 36 / 100), one row per step with a predicated tail
+    (132 ... 4096: every instantiated units-per-lane count, 1792 and 2304 on a padded one), two queries per pass beyond
+    2048 columns — and the scalar-capable generic kernel (dim % 4 != 0: 10; beyond 4096 columns: 4100)."""
     n = 3001 if dim <= 1024 else 1500
     raw = orc.synth_corpus(n, dim, seed=dim)
     cols = orc.synth_payload_columns(n, seed=dim)
@@ -164,17 +168,18 @@ def test_dimension_sweep_vs_oracle(dim):
         check_batch(E, Q, dewi32, ent32, k, eta, pref, "cosine", ids, sc, min_decisive_frac=0.8 if k <= 10 else 0.6)
 
 
-@pytest.mark.parametrize("dim", [16, 100, 768])
+@pytest.mark.parametrize("dim", [16, 100, 128, 384, 768, 1000, 3072])
 def test_l2_space_vs_oracle(dim):
-    n = 2000
+    n = 2000 if dim <= 1024 else 1000
     rs = np.random.RandomState(dim)
     raw = (rs.randn(n, dim) * 0.5).astype(np.float32)
     cols = orc.synth_payload_columns(n, seed=3)
     Q = (rs.randn(5, dim) * 0.5).astype(np.float32)
     c = _corpus(raw, cols, "l2")
     dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
-    ids, sc = c.search(Q, 10, 0.3, 0.0)
-    check_batch(raw, Q, dewi32, ent32, 10, 0.3, 0.0, "l2", ids, sc, min_decisive_frac=0.8)
+    for k in (10, 40, 150):       # per-workgroup lists, per-wave lists, dense keys
+        ids, sc = c.search(Q, k, 0.3, 0.0)
+        check_batch(raw, Q, dewi32, ent32, k, 0.3, 0.0, "l2", ids, sc, min_decisive_frac=0.8 if k <= 10 else 0.5)
 
 
 def test_ties_prefer_lower_row_and_zero_query():
