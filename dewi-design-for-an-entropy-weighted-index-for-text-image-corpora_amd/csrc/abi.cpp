@@ -208,11 +208,24 @@ enum class BatchPath { Rows, Depth, Big };
 struct BatchPlan {
   BatchPath path;
   int c_local;                 // candidates a shard of n_rows can contribute: min(n_candidates, n_rows)
-  KnnLayout rows;
+  KnnLayout rows;              // Rows: the batch itself; Depth / Big: the REPAIR of refused queries (same row kernels, keys from offset 0)
   dewi::MfmaF32Layout depth;
   dewi::MfmaLayout big;
-  size_t total;                // workspace bytes of the chosen path
+  size_t flags_off;            // Depth / Big: one u32 per query behind both layouts — raised by the select for a refused query
+  size_t total;                // workspace bytes of the chosen path (+ its repair)
 };
+
+// A matrix-core pass may refuse a query (survivor segment overflowed, error band wider than the sort: adversarial corpora,
+// ~4 % of the calls of scripts/fuzz_shadow_single.py).  The reference always answers (backends.py:414-481), so the batch does
+// too, behind the boundary: the select raises the query's flag instead of writing it off, and two fixed-shape launches on the
+// same stream — a row scan and a select that look at the flags and return at once when none is set — answer the flagged
+// queries exactly.  `corpus_elem_bytes` is the matrix the repair scans (the fp32 rows for a pre-selection over a bf16 shadow).
+void plan_repair(BatchPlan& P, size_t path_total, int64_t n_rows, int dim, int corpus_elem_bytes, int n_queries, int n_candidates,
+                 int cus) {
+  P.rows = layout_knn(n_rows, dim, corpus_elem_bytes, n_queries, n_candidates, cus);
+  P.flags_off = align_up(path_total > P.rows.total ? path_total : P.rows.total, 256);
+  P.total = P.flags_off + align_up(static_cast<size_t>(n_queries) * 4, 256);
+}
 
 BatchPlan plan_batch(int elem_type, int64_t n_rows, int dim, int n_queries, int n_candidates, int space, int cus) {
   BatchPlan P{};
@@ -225,17 +238,19 @@ BatchPlan plan_batch(int elem_type, int64_t n_rows, int dim, int n_queries, int 
   // kernels' arithmetic: batch_select); over a bf16 corpus l2 batches take the exact row kernels unless the calling thread
   // opted in to the approximate form (dewi_tuning_set batched_mfma = 2).
   const bool mfma = g_tuning.mfma != 0 && P.c_local == n_candidates &&
-                    (space == DEWI_SPACE_COSINE || elem_type == 0 || g_tuning.mfma == 2);
+                    (space == DEWI_SPACE_COSINE || elem_type == 0 || g_tuning.mfma == 2) &&
+                    dewi::scan_flagged_supported(dewi::plan_scan(n_rows, dim, elem_type ? 2 : 4, n_candidates, cus, g_tuning),
+                                                 elem_type ? 2 : 4);
   const bool depth_ok = mfma && dewi::mfma_f32_path_supported(elem_type, n_rows, dim, n_queries, n_candidates, space);
   const bool big_ok = mfma && elem_type == 1 && dewi::mfma_path_supported(n_rows, dim, n_queries, n_candidates, space);
   if (depth_ok && (elem_type == 0 || n_queries <= 32 || !big_ok)) {
     P.path = BatchPath::Depth;
     P.depth = dewi::plan_mfma_f32(elem_type, n_rows, dim, n_queries, n_candidates, cus);
-    P.total = P.depth.total;
+    plan_repair(P, P.depth.total, n_rows, dim, elem_type ? 2 : 4, n_queries, n_candidates, cus);
   } else if (big_ok) {
     P.path = BatchPath::Big;
     P.big = dewi::plan_mfma(n_rows, dim, n_queries, n_candidates, cus);
-    P.total = P.big.total;
+    plan_repair(P, P.big.total, n_rows, dim, elem_type ? 2 : 4, n_queries, n_candidates, cus);
   } else {
     P.path = BatchPath::Rows;
     P.rows = layout_knn(n_rows, dim, elem_type ? 2 : 4, n_queries, P.c_local, cus);
@@ -266,10 +281,35 @@ int batch_scan(const BatchPlan& P, const void* d_E, int elem_type, int64_t n_row
 // query of a matrix-core path carries id -2 there, -1 in the id output).
 // d_E / elem_type / dim / space: the corpus the scan ran over — the exact-refine mode of l2 over an fp32 corpus re-scores
 // its candidates from the rows themselves.
+// The repair of a matrix-core batch (plan_repair): flagged queries once more on the exact row kernels over `d_E`
+// (`elem_type`: its element type), keys from offset 0 of the workspace — the pass's own regions are dead by now.
+int batch_repair(const BatchPlan& P, char* ws, const void* d_E, int elem_type, int64_t n_rows, int dim, const float* d_Q,
+                 int n_queries, int n_candidates, int space, int k, const dewi::RerankParams& rp, const float* d_dewi32,
+                 const float* d_ent32, int64_t id_offset, int64_t* d_out_ids, float* d_out_scores, dewi_candidate* d_out_cand,
+                 hipStream_t stream) {
+  const KnnLayout& L = P.rows;
+  uint32_t* flags = reinterpret_cast<uint32_t*>(ws + P.flags_off);
+  uint64_t* keys = reinterpret_cast<uint64_t*>(ws + L.keys_off);
+  hipError_t e = elem_type ? dewi::launch_scan_flagged_bf16(L.plan, static_cast<const uint16_t*>(d_E), n_rows, dim, d_Q, n_queries,
+                                                            n_candidates, space, keys, flags, stream)
+                           : dewi::launch_scan_flagged_f32(L.plan, static_cast<const float*>(d_E), n_rows, dim, d_Q, n_queries,
+                                                           n_candidates, space, keys, flags, stream);
+  if (e != hipSuccess) return hip_fail(e, "repair scan launch");
+  if (n_candidates > dewi::kMaxSortCandidates) return fail(DEWI_ERR_UNSUPPORTED, "repair beyond %d candidates", dewi::kMaxSortCandidates);
+  const int sorted = L.plan.slots == 1 ? L.plan.n_lists : 0;
+  e = dewi::launch_select_rerank(keys, L.plan.keys_per_query, sorted, n_queries, n_candidates, k, rp, d_dewi32, d_ent32, id_offset,
+                                 d_out_ids, d_out_scores, d_out_cand, nullptr, dewi::SegmentLayout{}, stream,
+                                 dewi::RefineParams{nullptr, nullptr, nullptr, 0, 0.f, 0}, dewi::QueryFlags{flags, 2});
+  return e == hipSuccess ? DEWI_OK : hip_fail(e, "repair select launch");
+}
+
+// d_Q: the caller's RAW queries (the repair of a refused query scans for it again; exact-refine over a bf16 shadow
+// re-scores with them: `shadow`).
 int batch_select(const BatchPlan& P, void* d_ws, size_t ws_bytes, int n_queries, int n_candidates, int k,
                  const dewi::RerankParams& rp, const float* d_dewi32, const float* d_ent32, int64_t id_offset,
                  int64_t* d_out_ids, float* d_out_scores, dewi_candidate* d_out_cand, hipStream_t stream,
-                 const void* d_E, int elem_type, int dim, int space, const float* d_Q_shadow = nullptr) {
+                 const void* d_E, int elem_type, int64_t n_rows, int dim, int space, const float* d_Q, bool shadow = false) {
+  const float* d_Q_shadow = shadow ? d_Q : nullptr;
   if (!d_ws || ws_bytes < P.total) return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, P.total);
   char* ws = static_cast<char*>(d_ws);
   hipError_t e = hipSuccess;
@@ -310,8 +350,8 @@ int batch_select(const BatchPlan& P, void* d_ws, size_t ws_bytes, int n_queries,
   // workspace), or the 256-query pass over the bf16 SHADOW of an fp32 corpus (d_Q_shadow = the caller's raw queries)
   const bool refine_l2 = !big && space == DEWI_SPACE_L2 && elem_type == 0;
   const bool refine_shadow = d_Q_shadow != nullptr;
-  const bool refine = refine_l2 || refine_shadow;
-  if (refine && !d_E) return fail(DEWI_ERR_INVALID_ARG, "l2 over an fp32 corpus: the finish step needs the corpus pointer");
+  if (!d_E || !d_Q) return fail(DEWI_ERR_INVALID_ARG, "a matrix-core batch needs the corpus and the raw queries in its finish step (repair of refused queries)");
+  uint32_t* flags = reinterpret_cast<uint32_t*>(ws + P.flags_off);
   for (int g = 0; g < groups && e == hipSuccess; ++g) {
     const int q0 = g * per;
     const int nq = n_queries - q0 < per ? n_queries - q0 : per;
@@ -330,9 +370,11 @@ int batch_select(const BatchPlan& P, void* d_ws, size_t ws_bytes, int n_queries,
                                    d_out_ids ? d_out_ids + static_cast<int64_t>(q0) * k : nullptr,
                                    d_out_scores ? d_out_scores + static_cast<int64_t>(q0) * k : nullptr,
                                    d_out_cand ? d_out_cand + static_cast<int64_t>(q0) * n_candidates : nullptr, counts, seg, stream,
-                                   rf);
+                                   rf, dewi::QueryFlags{flags + q0, 1});
   }
-  return e == hipSuccess ? DEWI_OK : hip_fail(e, "select launch");
+  if (e != hipSuccess) return hip_fail(e, "select launch");
+  return batch_repair(P, ws, d_E, elem_type, n_rows, dim, d_Q, n_queries, n_candidates, space, k, rp, d_dewi32, d_ent32, id_offset,
+                      d_out_ids, d_out_scores, d_out_cand, stream);
 }
 
 // n_candidates_override <= 0: the reference's cut, min(2k, n_rows) (backends.py:439).
@@ -364,7 +406,65 @@ int knn_rerank_impl(const void* d_E, int elem_type, int64_t n_rows, int dim, con
   if (rc) return rc;
   const dewi::RerankParams rp = make_rerank(eta, pref, transform, space);
   return batch_select(P, d_ws, ws_bytes, n_queries, c, k, rp, d_dewi32, d_ent32, 0, d_out_ids, d_out_scores, nullptr, stream, d_E,
-                      elem_type, dim, space);
+                      elem_type, n_rows, dim, space, d_Q);
+}
+
+// Which route a search over an fp32 corpus WITH a bf16 shadow takes (dewi_knn_rerank_f32_shadow), from the shapes alone.
+enum class ShadowMode { Plain, Lists, Big, Depth };
+struct ShadowPlan {
+  ShadowMode mode;
+  int c;              // the reference's cut min(2k, n_rows)
+  int list_len;       // Lists: length of the per-workgroup lists the bf16 row kernel is asked for
+  KnnLayout lists;    // Lists: that scan's layout
+  BatchPlan P;        // the pass's layout (Big / Depth) and, for every mode but Plain, the repair + flags (plan_repair)
+};
+
+ShadowPlan plan_shadow(bool have_shadow, int64_t n_rows, int dim, int n_queries, int k, int space, int cus) {
+  ShadowPlan S{};
+  S.mode = ShadowMode::Plain;
+  const int64_t c64 = (2ll * k < n_rows) ? 2ll * k : n_rows;
+  S.c = static_cast<int>(c64 < (1ll << 30) ? c64 : (1ll << 30));
+  // the shadow pre-selects only where a matrix-core pass runs over it and the one-query search of the same corpus takes the
+  // row-per-wave kernel whose arithmetic the refinement repeats (dim 256 / 512 / 768 / 1024 / 1536: scan_rows_f32<U = dim / 256>, up to six
+  // 16-byte units per lane in the re-scoring); everything else is the plain search.  dim 1024 / 1536 have no 256-query pass
+  // (and 1536 no tuned bf16 row kernel: one query takes the depth-split pass too):
+  // its batches run the depth-split pass over the shadow in groups of 32 (2 GB instead of 4 GB per group at 1 M rows)
+  const bool usable = have_shadow && g_tuning.mfma != 0 && space == DEWI_SPACE_COSINE && k > 0 && k <= n_rows &&
+                      (dim == 256 || dim == 512 || dim == 768 || dim == 1024 || dim == 1536);
+  if (!usable) return S;
+  const bool use_big = n_queries > 32 && c64 <= 512 && dewi::mfma_path_supported(n_rows, dim, n_queries, S.c, space);
+  // (a SINGLE query takes the depth-split pass too: one pass over half the bytes + the exact re-scoring, 0.26 ms instead of
+  // the fp32 row scan's 0.43 at 1 M x 768; the pass itself has no lower limit on the batch, kMfmaMinQueries is a choice
+  // between it and the bf16 row kernels for a bf16 CORPUS)
+  const bool use_depth = !use_big && c64 <= 256 &&
+                         dewi::mfma_f32_path_supported(1, n_rows, dim, n_queries < dewi::kMfmaMinQueries ? dewi::kMfmaMinQueries : n_queries,
+                                                       S.c, space);
+  // ONE query with a small cut: the bf16 ROW kernel over the shadow (two launches instead of the pass's five: 0.222 ms scan
+  // at 1 M x 768) with per-workgroup lists long enough for the rows inside the error band, then the same exact re-scoring
+  // (select_rerank.hip refine_from_sorted_lists)
+  const int list_len = (n_queries == 1 && n_rows >= 64 * 1024) ? dewi::shadow_list_len(static_cast<int>(c64 < 64 ? c64 : 64)) : 0;
+  if (list_len > 0) {
+    S.lists = layout_knn(n_rows, dim, 2, 1, list_len, cus);
+    if (S.lists.plan.fast && S.lists.plan.slots == 1 && S.lists.plan.n_lists <= 4 * 64) {
+      S.mode = ShadowMode::Lists;
+      S.list_len = list_len;
+      plan_repair(S.P, S.lists.total, n_rows, dim, 4, 1, S.c, cus);   // the repair of a refused query: the plain fp32 scan
+      return S;
+    }
+  }
+  S.P.c_local = S.c;
+  if (use_big) {
+    S.mode = ShadowMode::Big;
+    S.P.path = BatchPath::Big;
+    S.P.big = dewi::plan_mfma(n_rows, dim, n_queries, S.c, cus, true);
+    plan_repair(S.P, S.P.big.total, n_rows, dim, 4, n_queries, S.c, cus);      // the repair scans the fp32 rows
+  } else if (use_depth) {
+    S.mode = ShadowMode::Depth;    // 1..32 queries (and larger batches the 256-query pass does not take): passes of 32 over the shadow
+    S.P.path = BatchPath::Depth;
+    S.P.depth = dewi::plan_mfma_f32(1, n_rows, dim, n_queries, S.c, cus, true);
+    plan_repair(S.P, S.P.depth.total, n_rows, dim, 4, n_queries, S.c, cus);
+  }
+  return S;
 }
 
 }  // namespace
@@ -445,7 +545,38 @@ size_t dewi_knn_workspace_bytes(int64_t n_rows, int dim, int n_queries, int n_ca
       }
     }
   }
-  return a;  // valid for either element type and every path (small-batch scans, bf16 / fp32 matrix-core)
+  // valid for either element type and every path (small-batch scans, bf16 / fp32 matrix-core) + the per-query refusal
+  // flags of a matrix-core batch behind the larger of its own layout and its repair's (plan_repair)
+  return align_up(a, 256) + align_up(static_cast<size_t>(n_queries) * 4, 256);
+}
+
+int dewi_knn_scan_kernel(int elem_type, int64_t n_rows, int dim, int n_queries, int n_candidates, int space, char* out,
+                         size_t out_bytes) {
+  if (!out || out_bytes < 16) return fail(DEWI_ERR_INVALID_ARG, "name buffer too small");
+  if (n_rows <= 0 || dim <= 0 || n_queries <= 0 || n_candidates <= 0) return fail(DEWI_ERR_INVALID_ARG, "non-positive size");
+  DeviceInfo dev;
+  int rc = ensure_device(dev);
+  if (rc) return rc;
+  const BatchPlan P = plan_batch(elem_type, n_rows, dim, n_queries, n_candidates < n_rows ? n_candidates : static_cast<int>(n_rows),
+                                 space, dev.cus);
+  const char* e = elem_type ? "bf16" : "f32";
+  if (P.path == BatchPath::Depth) {
+    snprintf(out, out_bytes, "mfma_scan_f32<%s", elem_type ? "true" : "false");
+  } else if (P.path == BatchPath::Big) {
+    snprintf(out, out_bytes, "mfma_scan_bf16_s16");
+  } else {
+    const dewi::ScanPlan& p = P.rows.plan;
+    const int nq = n_queries >= p.nq_max ? p.nq_max : 1;
+    switch (p.kind) {
+      case dewi::kScanFast: snprintf(out, out_bytes, "scan_rows_%s", e); break;
+      case dewi::kScanAnyLong: snprintf(out, out_bytes, "scan_rows_any<%d, %d, %d, %d, %d, %d>", elem_type ? 1 : 0, p.u_pad,
+                                        nq > 1 ? p.rows_per_iter_batch : p.rows_per_iter, nq, space, p.slots); break;
+      case dewi::kScanAnyShort: snprintf(out, out_bytes, "scan_short_rows_any<%d, %d, %d, %d, %d>", elem_type ? 1 : 0,
+                                         p.rows_per_iter / (64 >> p.log2p), nq, space, p.slots); break;
+      default: snprintf(out, out_bytes, "scan_generic_%s", e); break;
+    }
+  }
+  return DEWI_OK;
 }
 
 int dewi_knn_rerank_f32(const float* d_E, int64_t n_rows, int dim, const float* d_Q, int n_queries,
@@ -466,70 +597,60 @@ int dewi_knn_rerank_f32_shadow(const float* d_E, const uint16_t* d_E_bf16, int64
   DeviceInfo dev;
   rc = ensure_device(dev);
   if (rc) return rc;
-  const int64_t c64 = (2ll * k < n_rows) ? 2ll * k : n_rows;
-  // the shadow pre-selects only where a matrix-core pass runs over it and the one-query search of the same corpus takes the
-  // row-per-wave kernel whose arithmetic the refinement repeats (dim 256 / 512 / 768 / 1024 / 1536: scan_rows_f32<U = dim / 256>, up to six
-  // 16-byte units per lane in the re-scoring); everything else is the plain search.  dim 1024 / 1536 have no 256-query pass
-  // (and 1536 no bf16 row kernel: one query takes the depth-split pass too):
-  // its batches run the depth-split pass over the shadow in groups of 32 (2 GB instead of 4 GB per group at 1 M rows)
-  const bool usable = d_E_bf16 != nullptr && g_tuning.mfma != 0 && space == DEWI_SPACE_COSINE && k > 0 && k <= n_rows &&
-                      (dim == 256 || dim == 512 || dim == 768 || dim == 1024 || dim == 1536);
-  const bool use_big = usable && n_queries > 32 && c64 <= 512 &&
-                       dewi::mfma_path_supported(n_rows, dim, n_queries, static_cast<int>(c64), space);
-  // (a SINGLE query takes the depth-split pass too: one pass over half the bytes + the exact re-scoring, 0.26 ms instead of
-  // the fp32 row scan's 0.43 at 1 M x 768; the pass itself has no lower limit on the batch, kMfmaMinQueries is a choice
-  // between it and the bf16 row kernels for a bf16 CORPUS)
-  const bool use_depth = usable && !use_big && c64 <= 256 &&
-                         dewi::mfma_f32_path_supported(1, n_rows, dim, n_queries < dewi::kMfmaMinQueries ? dewi::kMfmaMinQueries : n_queries,
-                                                       static_cast<int>(c64), space);
-  // ONE query with a small cut: the bf16 ROW kernel over the shadow (two launches instead of the pass's five: 0.222 ms scan
-  // at 1 M x 768) with per-workgroup lists long enough for the rows inside the error band, then the same exact re-scoring
-  // (select_rerank.hip refine_from_sorted_lists)
-  const int list_len = (usable && n_queries == 1 && n_rows >= 64 * 1024) ? dewi::shadow_list_len(static_cast<int>(c64 < 64 ? c64 : 64)) : 0;
-  if (list_len > 0) {
-    if (!d_dewi32 || !d_ent32 || !d_out_ids || !d_out_scores) return fail(DEWI_ERR_INVALID_ARG, "null payload or output pointer");
-    const KnnLayout L = layout_knn(n_rows, dim, 2, 1, list_len, dev.cus);
-    if (L.plan.fast && L.plan.slots == 1 && L.plan.n_lists <= 4 * 64) {
-      if (!d_workspace || workspace_bytes < L.total)
-        return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, L.total);
-      char* ws = static_cast<char*>(d_workspace);
-      rc = run_scan(L, d_E_bf16, 1, n_rows, dim, d_Q, 1, list_len, space, ws, stream);
-      if (rc) return rc;
-      const dewi::RefineParams rf{d_E, d_Q, nullptr, dim, dewi::shadow_margin(dim), DEWI_SPACE_COSINE, list_len};
-      const hipError_t e = dewi::launch_select_rerank(reinterpret_cast<const uint64_t*>(ws + L.keys_off), L.plan.keys_per_query,
-                                                      L.plan.n_lists, 1, static_cast<int>(c64), k,
-                                                      make_rerank(eta, entropy_pref, DEWI_SIM_RAW, space), d_dewi32, d_ent32, 0,
-                                                      d_out_ids, d_out_scores, nullptr, nullptr, dewi::SegmentLayout{}, stream, rf);
-      return e == hipSuccess ? DEWI_OK : hip_fail(e, "select launch (one query, bf16 shadow)");
-    }
-  }
-  if (!use_big && !use_depth)
+  const ShadowPlan S = plan_shadow(d_E_bf16 != nullptr, n_rows, dim, n_queries, k, space, dev.cus);
+  if (S.mode == ShadowMode::Plain)
     return knn_rerank_impl(d_E, 0, n_rows, dim, d_Q, n_queries, d_dewi32, d_ent32, k, eta, entropy_pref, space, d_out_ids,
                            d_out_scores, d_workspace, workspace_bytes, stream_);
   if (!d_dewi32 || !d_ent32 || !d_out_ids || !d_out_scores) return fail(DEWI_ERR_INVALID_ARG, "null payload or output pointer");
-  const int c = static_cast<int>(c64);
-  BatchPlan P{};
-  P.c_local = c;
-  if (use_big) {
-    P.path = BatchPath::Big;
-    P.big = dewi::plan_mfma(n_rows, dim, n_queries, c, dev.cus, true);
-    P.total = P.big.total;
-  } else {
-    P.path = BatchPath::Depth;     // 1..32 queries (and larger batches the 256-query pass does not take): passes of 32 over the shadow
-    P.depth = dewi::plan_mfma_f32(1, n_rows, dim, n_queries, c, dev.cus, true);
-    P.total = P.depth.total;
-  }
+  const BatchPlan& P = S.P;
   if (!d_workspace || workspace_bytes < P.total) return fail(DEWI_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, P.total);
+  char* ws = static_cast<char*>(d_workspace);
+  const dewi::RerankParams rp = make_rerank(eta, entropy_pref, DEWI_SIM_RAW, space);
+  if (S.mode == ShadowMode::Lists) {
+    const KnnLayout& L = S.lists;
+    rc = run_scan(L, d_E_bf16, 1, n_rows, dim, d_Q, 1, S.list_len, space, ws, stream);
+    if (rc) return rc;
+    const dewi::RefineParams rf{d_E, d_Q, nullptr, dim, dewi::shadow_margin(dim), DEWI_SPACE_COSINE, S.list_len};
+    const hipError_t e = dewi::launch_select_rerank(reinterpret_cast<const uint64_t*>(ws + L.keys_off), L.plan.keys_per_query,
+                                                    L.plan.n_lists, 1, S.c, k, rp, d_dewi32, d_ent32, 0, d_out_ids, d_out_scores,
+                                                    nullptr, nullptr, dewi::SegmentLayout{}, stream, rf,
+                                                    dewi::QueryFlags{reinterpret_cast<uint32_t*>(ws + P.flags_off), 1});
+    if (e != hipSuccess) return hip_fail(e, "select launch (one query, bf16 shadow)");
+    return batch_repair(P, ws, d_E, 0, n_rows, dim, d_Q, 1, S.c, space, k, rp, d_dewi32, d_ent32, 0, d_out_ids, d_out_scores,
+                        nullptr, stream);
+  }
   // scores from bf16(e), bf16(q) are within shadow_margin of the fp32 row kernels': the sample's c-th best minus the bound is
   // a lower bound of the exact c-th best, and a row may score that much lower here than exactly -> thresholds - 2 bounds
   const float bias = 2.f * dewi::shadow_margin(dim);
-  hipError_t e = use_big ? dewi::launch_mfma_bf16(P.big, d_E_bf16, n_rows, dim, d_Q, n_queries, c, space,
-                                                  static_cast<char*>(d_workspace), dev.cus, stream, bias)
-                         : dewi::launch_mfma_f32(P.depth, 1, d_E_bf16, n_rows, dim, d_Q, n_queries, c, space,
-                                                 static_cast<char*>(d_workspace), stream, bias);
+  hipError_t e = S.mode == ShadowMode::Big
+                     ? dewi::launch_mfma_bf16(P.big, d_E_bf16, n_rows, dim, d_Q, n_queries, S.c, space, ws, dev.cus, stream, bias)
+                     : dewi::launch_mfma_f32(P.depth, 1, d_E_bf16, n_rows, dim, d_Q, n_queries, S.c, space, ws, stream, bias);
   if (e != hipSuccess) return hip_fail(e, "mfma scan launch (bf16 shadow)");
-  return batch_select(P, d_workspace, workspace_bytes, n_queries, c, k, make_rerank(eta, entropy_pref, DEWI_SIM_RAW, space), d_dewi32,
-                      d_ent32, 0, d_out_ids, d_out_scores, nullptr, stream, d_E, 0, dim, space, d_Q);
+  return batch_select(P, d_workspace, workspace_bytes, n_queries, S.c, k, rp, d_dewi32, d_ent32, 0, d_out_ids, d_out_scores, nullptr,
+                      stream, d_E, 0, n_rows, dim, space, d_Q, true);
+}
+
+int dewi_knn_refusal_flags(int elem_type, int through_shadow, int64_t n_rows, int dim, int n_queries, int k, int n_candidates,
+                           int space, size_t* out_offset_bytes) {
+  if (!out_offset_bytes) return fail(DEWI_ERR_INVALID_ARG, "null pointer");
+  if (n_rows <= 0 || dim <= 0 || n_queries <= 0) return fail(DEWI_ERR_INVALID_ARG, "non-positive size");
+  DeviceInfo dev;
+  int rc = ensure_device(dev);
+  if (rc) return rc;
+  *out_offset_bytes = static_cast<size_t>(-1);   // row kernels: nothing can be refused, no flags
+  if (through_shadow && elem_type == 0) {
+    const ShadowPlan S = plan_shadow(true, n_rows, dim, n_queries, k, space, dev.cus);
+    if (S.mode != ShadowMode::Plain) {
+      *out_offset_bytes = S.P.flags_off;
+      return DEWI_OK;
+    }
+  }
+  int64_t c64 = n_candidates > 0 ? n_candidates : 2ll * k;
+  if (c64 > n_rows) c64 = n_rows;
+  if (c64 <= 0 || c64 > (1ll << 30)) return DEWI_OK;
+  const BatchPlan P = plan_batch(elem_type, n_rows, dim, n_queries, static_cast<int>(c64), space, dev.cus);
+  if (P.path != BatchPath::Rows) *out_offset_bytes = P.flags_off;
+  return DEWI_OK;
 }
 
 int dewi_knn_rerank_candidates(const void* d_E, int elem_type, int64_t n_rows, int dim, const float* d_Q, int n_queries,
@@ -566,7 +687,7 @@ int dewi_knn_scan(const void* d_E, int elem_type, int64_t n_rows, int dim, const
 }
 
 int dewi_knn_finish(void* d_workspace, size_t workspace_bytes, const void* d_E, int elem_type, int64_t n_rows, int dim,
-                    int n_queries, int n_candidates, int space, int k, double eta, double entropy_pref,
+                    const float* d_Q, int n_queries, int n_candidates, int space, int k, double eta, double entropy_pref,
                     const float* d_dewi32, const float* d_ent32, int64_t id_offset, int64_t* d_out_ids,
                     float* d_out_scores, dewi_candidate* d_out_cand, void* stream_) {
   if (n_rows <= 0 || dim <= 0 || n_queries <= 0) return fail(DEWI_ERR_INVALID_ARG, "non-positive size");
@@ -590,7 +711,7 @@ int dewi_knn_finish(void* d_workspace, size_t workspace_bytes, const void* d_E, 
   return batch_select(P, d_workspace, workspace_bytes, n_queries, n_candidates, records ? 0 : k,
                       make_rerank(records ? 0.0 : eta, records ? 0.0 : entropy_pref, DEWI_SIM_RAW, space), d_dewi32, d_ent32,
                       id_offset, records ? nullptr : d_out_ids, records ? nullptr : d_out_scores, d_out_cand,
-                      static_cast<hipStream_t>(stream_), d_E, elem_type, dim, space);
+                      static_cast<hipStream_t>(stream_), d_E, elem_type, n_rows, dim, space, d_Q);
 }
 
 int dewi_knn_rerank_bf16(const uint16_t* d_E, int64_t n_rows, int dim, const float* d_Q, int n_queries,
@@ -622,7 +743,7 @@ int dewi_knn_candidates(const void* d_E, int elem_type, int64_t n_rows, int dim,
   rc = batch_scan(P, d_E, elem_type, n_rows, dim, d_Q, n_queries, n_candidates, space, d_workspace, workspace_bytes, dev.cus, stream);
   if (rc) return rc;
   return batch_select(P, d_workspace, workspace_bytes, n_queries, n_candidates, 0, make_rerank(0.0, 0.0), d_dewi32, d_ent32,
-                      id_offset, nullptr, nullptr, d_out, stream, d_E, elem_type, dim, space);
+                      id_offset, nullptr, nullptr, d_out, stream, d_E, elem_type, n_rows, dim, space, d_Q);
 }
 
 size_t dewi_merge_workspace_bytes(int n_lists, int n_queries, int list_len, int n_candidates) {

@@ -27,13 +27,12 @@ namespace dewi {
 // S = key slots per lane: 1 (c <= 64, block-merged sorted output, one list per workgroup),
 // 4 (c <= 256, one unsorted list per wave) or 0 (dense: one key per row).
 template <int U, int R, int NQ, int SPACE, int S, bool NT>
-__global__ __launch_bounds__(kScanThreads) void scan_rows_f32(const float* __restrict__ E, int64_t n_rows,
-                                                              const float* __restrict__ Q, int n_candidates,
-                                                              uint64_t* __restrict__ keys,
-                                                              int64_t keys_per_query) {
+__device__ __forceinline__ void scan_rows_f32_body(const float* __restrict__ E, int64_t n_rows,
+                                                   const float* __restrict__ Q, int n_candidates,
+                                                   uint64_t* __restrict__ keys, int64_t keys_per_query,
+                                                   MergeShared& merge_buf) {
   constexpr int D4 = 64 * U;  // float4 units per row
   constexpr bool DENSE = S == 0;
-  __shared__ MergeShared merge_buf;
   const int lane = lane_id();
   const int wave_in_block = static_cast<int>(threadIdx.x) >> 6;
   const int64_t gwave = static_cast<int64_t>(blockIdx.x) * (kScanThreads / kWave) + wave_in_block;
@@ -125,6 +124,30 @@ __global__ __launch_bounds__(kScanThreads) void scan_rows_f32(const float* __res
 #pragma unroll
     for (int qi = 0; qi < NQ; ++qi)
       lst[qi].store(keys + qi * keys_per_query + gwave * n_candidates, n_candidates, lane);
+  }
+}
+
+template <int U, int R, int NQ, int SPACE, int S, bool NT>
+__global__ __launch_bounds__(kScanThreads) void scan_rows_f32(const float* __restrict__ E, int64_t n_rows,
+                                                              const float* __restrict__ Q, int n_candidates,
+                                                              uint64_t* __restrict__ keys,
+                                                              int64_t keys_per_query) {
+  __shared__ MergeShared merge_buf;
+  scan_rows_f32_body<U, R, NQ, SPACE, S, NT>(E, n_rows, Q, n_candidates, keys, keys_per_query, merge_buf);
+}
+
+// REPAIR form (abi.cpp batch_repair): one launch answers every query of a batch whose flag is set — the queries a
+// matrix-core pass refused — one corpus pass each, and returns at once when none is (the usual case: one ~3 us dispatch).
+template <int U, int R, int SPACE, int S>
+__global__ __launch_bounds__(kScanThreads) void scan_rows_f32_flagged(const float* __restrict__ E, int64_t n_rows,
+                                                                      const float* __restrict__ Q, int n_candidates,
+                                                                      uint64_t* __restrict__ keys, int64_t keys_per_query,
+                                                                      const uint32_t* __restrict__ flags, int n_queries) {
+  __shared__ MergeShared merge_buf;
+  for (int q = 0; q < n_queries; ++q) {
+    if (flags[q] == 0u) continue;   // wave-uniform
+    scan_rows_f32_body<U, R, 1, SPACE, S, true>(E, n_rows, Q + static_cast<int64_t>(q) * (256 * U), n_candidates,
+                                                keys + static_cast<int64_t>(q) * keys_per_query, keys_per_query, merge_buf);
   }
 }
 
@@ -353,6 +376,7 @@ ScanPlan plan_scan(int64_t n_rows, int dim, int elem_bytes, int n_candidates, in
   p.kind = p.fast ? kScanFast : kScanGeneric;
   p.nq_max = 4;
   p.units = p.u_pad = p.log2p = 0;
+  p.level = 1;
   // rows of whole 16-byte units outside the tuned set: the any-width kernels (scan_any.hpp), queries in registers
   const int cols_per_unit = elem_bytes == 2 ? 8 : 4;
   if (!p.fast && dim % cols_per_unit == 0) {
@@ -370,8 +394,10 @@ ScanPlan plan_scan(int64_t n_rows, int dim, int elem_bytes, int n_candidates, in
       for (int v : pads)
         if (v >= need) { p.u_pad = v; break; }
       if (p.u_pad > 8) p.nq_max = 2;
-      p.rows_per_iter = any_rows(p.u_pad, 1);
-      p.rows_per_iter_batch = any_rows(p.u_pad, p.nq_max);
+      // (sweeps: dewi_tuning_set rows_per_iter = 1, 2, 3 picks the level instead of the width)
+      p.level = tuning.rows_per_iter > 0 ? (tuning.rows_per_iter - 1) % kAnyLevels : any_level(n_units);
+      p.rows_per_iter = any_rows(p.u_pad, 1, p.level);
+      p.rows_per_iter_batch = any_rows(p.u_pad, p.nq_max, p.level);
     }
   }
   p.raw_queries = p.kind != kScanGeneric;
@@ -468,6 +494,55 @@ static hipError_t launch_scan_impl(const ScanPlan& plan, const float* E, int64_t
     launch_generic<NQ, SPACE, S>(plan, dim, E, n_rows, Qn, c, keys, stream);
   }
   return hipGetLastError();
+}
+
+template <int U, int SPACE>
+static hipError_t launch_flagged_s(const ScanPlan& plan, const float* E, int64_t n_rows, const float* Q, int n_queries, int c,
+                                   uint64_t* keys, const uint32_t* flags, hipStream_t stream) {
+  constexpr int R = U == 1 ? 4 : (U == 2 ? 2 : 1);
+  switch (plan.slots) {
+    case 0:
+      hipLaunchKernelGGL((scan_rows_f32_flagged<U, R, SPACE, 0>), dim3(plan.blocks), dim3(kScanThreads), 0, stream, E, n_rows, Q, c,
+                         keys, plan.keys_per_query, flags, n_queries);
+      break;
+    case 1:
+      hipLaunchKernelGGL((scan_rows_f32_flagged<U, R, SPACE, 1>), dim3(plan.blocks), dim3(kScanThreads), 0, stream, E, n_rows, Q, c,
+                         keys, plan.keys_per_query, flags, n_queries);
+      break;
+    default:
+      hipLaunchKernelGGL((scan_rows_f32_flagged<U, R, SPACE, kMaxSlots>), dim3(plan.blocks), dim3(kScanThreads), 0, stream, E, n_rows,
+                         Q, c, keys, plan.keys_per_query, flags, n_queries);
+      break;
+  }
+  return hipGetLastError();
+}
+
+bool scan_flagged_supported(const ScanPlan& plan, int elem_bytes) {
+  if (plan.kind == kScanFast) return true;
+  // any-width kernels: the widths the matrix-core passes of a bf16 corpus run at outside the dim = 256 U set
+  // (128, 384, 640: the 256-query pass; 1536: the depth-split pass)
+  return elem_bytes == 2 && (plan.kind == kScanAnyShort || (plan.kind == kScanAnyLong && plan.u_pad <= 3));
+}
+
+hipError_t launch_scan_flagged_f32(const ScanPlan& plan, const float* d_E, int64_t n_rows, int dim, const float* d_q_raw,
+                                   int n_queries, int n_candidates, int space, uint64_t* d_keys, const uint32_t* d_flags,
+                                   hipStream_t stream) {
+  if (plan.kind != kScanFast) return hipErrorInvalidValue;
+#define DEWI_FLAGGED(UU)                                                                                                 \
+  case UU:                                                                                                               \
+    return space == DEWI_SPACE_COSINE                                                                                    \
+               ? launch_flagged_s<UU, DEWI_SPACE_COSINE>(plan, d_E, n_rows, d_q_raw, n_queries, n_candidates, d_keys, d_flags, stream) \
+               : launch_flagged_s<UU, DEWI_SPACE_L2>(plan, d_E, n_rows, d_q_raw, n_queries, n_candidates, d_keys, d_flags, stream);
+  switch (dim / 256) {
+    DEWI_FLAGGED(1)
+    DEWI_FLAGGED(2)
+    DEWI_FLAGGED(3)
+    DEWI_FLAGGED(4)
+    DEWI_FLAGGED(6)
+    default: break;
+  }
+#undef DEWI_FLAGGED
+  return hipErrorInvalidValue;
 }
 
 hipError_t launch_scan_f32(const ScanPlan& plan, const float* d_E, int64_t n_rows, int dim, const float* d_q_raw,

@@ -20,14 +20,13 @@
 namespace dewi {
 
 template <int H, int NQ, int SPACE, int S, bool NT>
-__global__ __launch_bounds__(kScanThreads) void scan_rows_bf16(const uint16_t* __restrict__ E, int64_t n_rows,
-                                                               const float* __restrict__ Q, int n_candidates,
-                                                               uint64_t* __restrict__ keys,
-                                                               int64_t keys_per_query) {
+__device__ __forceinline__ void scan_rows_bf16_body(const uint16_t* __restrict__ E, int64_t n_rows,
+                                                    const float* __restrict__ Q, int n_candidates,
+                                                    uint64_t* __restrict__ keys, int64_t keys_per_query,
+                                                    MergeShared& merge_buf) {
   constexpr int D = 256 * H;          // columns
   constexpr int UPR = 32 * H;         // 16-byte units per row
   constexpr bool DENSE = S == 0;
-  __shared__ MergeShared merge_buf;
   const int lane = lane_id();
   const int wave_in_block = static_cast<int>(threadIdx.x) >> 6;
   const int64_t gwave = static_cast<int64_t>(blockIdx.x) * (kScanThreads / kWave) + wave_in_block;
@@ -174,6 +173,29 @@ __global__ __launch_bounds__(kScanThreads) void scan_rows_bf16(const uint16_t* _
   }
 }
 
+template <int H, int NQ, int SPACE, int S, bool NT>
+__global__ __launch_bounds__(kScanThreads) void scan_rows_bf16(const uint16_t* __restrict__ E, int64_t n_rows,
+                                                               const float* __restrict__ Q, int n_candidates,
+                                                               uint64_t* __restrict__ keys,
+                                                               int64_t keys_per_query) {
+  __shared__ MergeShared merge_buf;
+  scan_rows_bf16_body<H, NQ, SPACE, S, NT>(E, n_rows, Q, n_candidates, keys, keys_per_query, merge_buf);
+}
+
+// REPAIR form: every flagged query of a batch, one corpus pass each, in one launch (see scan_rows_f32_flagged)
+template <int H, int SPACE, int S>
+__global__ __launch_bounds__(kScanThreads) void scan_rows_bf16_flagged(const uint16_t* __restrict__ E, int64_t n_rows,
+                                                                       const float* __restrict__ Q, int n_candidates,
+                                                                       uint64_t* __restrict__ keys, int64_t keys_per_query,
+                                                                       const uint32_t* __restrict__ flags, int n_queries) {
+  __shared__ MergeShared merge_buf;
+  for (int q = 0; q < n_queries; ++q) {
+    if (flags[q] == 0u) continue;   // wave-uniform
+    scan_rows_bf16_body<H, 1, SPACE, S, true>(E, n_rows, Q + static_cast<int64_t>(q) * (256 * H), n_candidates,
+                                              keys + static_cast<int64_t>(q) * keys_per_query, keys_per_query, merge_buf);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Generic path: any dim.  G lanes per row; queries arrive normalised and bf16-rounded as fp32.
 // VEC = 8 (16-byte loads) when dim % 8 == 0, else scalar.
@@ -295,6 +317,48 @@ static hipError_t launch_bf16_impl(const ScanPlan& plan, const uint16_t* E, int6
                        n_rows, dim, Qn, plan.group, c, keys, plan.keys_per_query);
   }
   return hipGetLastError();
+}
+
+template <int H, int SPACE>
+static hipError_t launch_flagged_bf16_s(const ScanPlan& plan, const uint16_t* E, int64_t n_rows, const float* Q, int n_queries, int c,
+                                        uint64_t* keys, const uint32_t* flags, hipStream_t stream) {
+  switch (plan.slots) {
+    case 0:
+      hipLaunchKernelGGL((scan_rows_bf16_flagged<H, SPACE, 0>), dim3(plan.blocks), dim3(kScanThreads), 0, stream, E, n_rows, Q, c, keys,
+                         plan.keys_per_query, flags, n_queries);
+      break;
+    case 1:
+      hipLaunchKernelGGL((scan_rows_bf16_flagged<H, SPACE, 1>), dim3(plan.blocks), dim3(kScanThreads), 0, stream, E, n_rows, Q, c, keys,
+                         plan.keys_per_query, flags, n_queries);
+      break;
+    default:
+      hipLaunchKernelGGL((scan_rows_bf16_flagged<H, SPACE, kMaxSlots>), dim3(plan.blocks), dim3(kScanThreads), 0, stream, E, n_rows, Q,
+                         c, keys, plan.keys_per_query, flags, n_queries);
+      break;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_scan_flagged_bf16(const ScanPlan& plan, const uint16_t* d_E, int64_t n_rows, int dim, const float* d_q_raw,
+                                    int n_queries, int n_candidates, int space, uint64_t* d_keys, const uint32_t* d_flags,
+                                    hipStream_t stream) {
+  if (plan.kind == kScanAnyLong || plan.kind == kScanAnyShort)
+    return launch_scan_any_flagged_bf16(plan, d_E, n_rows, dim, d_q_raw, n_queries, n_candidates, space, d_keys, d_flags, stream);
+  if (plan.kind != kScanFast) return hipErrorInvalidValue;
+#define DEWI_FLAGGED(HH)                                                                                                      \
+  case HH:                                                                                                                    \
+    return space == DEWI_SPACE_COSINE                                                                                         \
+               ? launch_flagged_bf16_s<HH, DEWI_SPACE_COSINE>(plan, d_E, n_rows, d_q_raw, n_queries, n_candidates, d_keys, d_flags, stream) \
+               : launch_flagged_bf16_s<HH, DEWI_SPACE_L2>(plan, d_E, n_rows, d_q_raw, n_queries, n_candidates, d_keys, d_flags, stream);
+  switch (dim / 256) {
+    DEWI_FLAGGED(1)
+    DEWI_FLAGGED(2)
+    DEWI_FLAGGED(3)
+    DEWI_FLAGGED(4)
+    default: break;
+  }
+#undef DEWI_FLAGGED
+  return hipErrorInvalidValue;
 }
 
 hipError_t launch_scan_bf16(const ScanPlan& plan, const uint16_t* d_E, int64_t n_rows, int dim, const float* d_q_raw,

@@ -64,6 +64,7 @@ struct ScanPlan {
   int units;          // any-width kernels: 16-byte units per row
   int u_pad;          // kScanAnyLong: units per lane the instantiated kernel holds (>= ceil(units / 64))
   int log2p;          // kScanAnyShort: log2 of the lanes that share a row
+  int level;          // kScanAnyLong: which rows-in-flight choice of its units-per-lane count (scan_any.hpp any_level / any_rows)
   int nq_max;         // most queries one corpus pass of the row kernel serves besides 1 (4; 2 for rows beyond 512 units)
   bool raw_queries;   // the kernel normalises the raw queries itself (everything but kScanGeneric)
   int64_t keys_per_query;  // number of uint64 keys the scan emits per query
@@ -105,6 +106,20 @@ hipError_t launch_scan_any_f32(const ScanPlan& plan, const float* d_E, int64_t n
                                int nq, int n_candidates, int space, uint64_t* d_keys, hipStream_t stream);
 hipError_t launch_scan_any_bf16(const ScanPlan& plan, const uint16_t* d_E, int64_t n_rows, int dim, const float* d_q_raw, int q0,
                                 int nq, int n_candidates, int space, uint64_t* d_keys, hipStream_t stream);
+
+// REPAIR launches (abi.cpp batch_repair): ONE launch scans the corpus once for every query q of [0, n_queries) whose
+// d_flags[q] != 0 (raw queries, keys at d_keys + q * plan.keys_per_query) and returns at once when no flag is set.
+// scan_flagged_supported: the row-kernel plans these launches exist for (every shape a matrix-core pass runs at).
+bool scan_flagged_supported(const ScanPlan& plan, int elem_bytes);
+hipError_t launch_scan_flagged_f32(const ScanPlan& plan, const float* d_E, int64_t n_rows, int dim, const float* d_q_raw,
+                                   int n_queries, int n_candidates, int space, uint64_t* d_keys, const uint32_t* d_flags,
+                                   hipStream_t stream);
+hipError_t launch_scan_flagged_bf16(const ScanPlan& plan, const uint16_t* d_E, int64_t n_rows, int dim, const float* d_q_raw,
+                                    int n_queries, int n_candidates, int space, uint64_t* d_keys, const uint32_t* d_flags,
+                                    hipStream_t stream);
+hipError_t launch_scan_any_flagged_bf16(const ScanPlan& plan, const uint16_t* d_E, int64_t n_rows, int dim, const float* d_q_raw,
+                                        int n_queries, int n_candidates, int space, uint64_t* d_keys, const uint32_t* d_flags,
+                                        hipStream_t stream);
 
 // ---- knn_scan_bf16.hip: the same pass over a bf16 corpus
 hipError_t launch_scan_bf16(const ScanPlan& plan, const uint16_t* d_E, int64_t n_rows, int dim, const float* d_q_raw,
@@ -216,11 +231,20 @@ inline int shadow_list_len(int n_candidates) {
   if (n_candidates > 32) return 0;
   return n_candidates <= 16 ? 32 : 2 * n_candidates;
 }
+// Per-query refusal flags of a batch (one u32 per query, in the caller's workspace).  mode 1: the launch WRITES them — 1
+// for a query it could not answer (survivor segment overflowed, error band wider than the sort), 0 otherwise — and leaves
+// the outputs of a refused query untouched; mode 2: the launch ANSWERS only flagged queries (the repair's select over the row
+// kernels' keys) and returns at once for the others.  p == NULL: no flags (a refused query is marked id -1 / -2 in its outputs).
+struct QueryFlags {
+  uint32_t* p;
+  int mode;
+};
 hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, int sorted_lists, int n_queries,
                                 int n_candidates, int k, const RerankParams& rp, const float* d_dewi32, const float* d_ent32,
                                 int64_t id_offset, int64_t* d_out_ids, float* d_out_scores,
                                 dewi_candidate* d_out_cand, const uint32_t* d_counts, const SegmentLayout& seg,
-                                hipStream_t stream, const RefineParams& refine = RefineParams{nullptr, nullptr, nullptr, 0, 0.f, 0});
+                                hipStream_t stream, const RefineParams& refine = RefineParams{nullptr, nullptr, nullptr, 0, 0.f, 0},
+                                const QueryFlags& flags = QueryFlags{nullptr, 0});
 // c > kMaxSortCandidates: dense keys [n_queries][keys_per_query] in, scratch g1/g2 [n_queries][p2].
 // d_out_cand != NULL: n_out records per query (the shard's candidates) instead of final results.
 hipError_t launch_select_rerank_large(const uint64_t* d_keys, int64_t keys_per_query, int n_queries, int n_candidates,

@@ -82,20 +82,33 @@ struct UnitFrag<1, SPACE> {   // bf16 rows: 8 columns per unit; the prepared que
   }
 };
 
-// rows a wave issues before its first reduction (~3-4 KiB in flight per wave, as the dim = 256 U kernels)
-#ifndef DEWI_ANY_R1
-#define DEWI_ANY_R1 4
-#endif
-#ifndef DEWI_ANY_R2
-#define DEWI_ANY_R2 2
-#endif
+// Rows a wave issues before its first reduction.  Measured on MI355X at 3 GB (scripts/sweep_any.sh, profiles/r04): rows
+// that are not whole KiB want ~5-6 KiB in flight per wave — more than the 3 KiB of the dim = 768 kernel, because the
+// reduction and the list offer come round more often per byte and a wave shares its first and last cache line with its
+// neighbours.  TB/s by (row bytes, rows in flight): 640 B: 8 rows 6.47, 12 rows 6.92; 768 B: 8 -> 6.99, 12 -> 6.87;
+// 1040 B: 3 -> 5.81, 4 -> 6.45; 1280 B: 3 -> 6.67, 4 -> 7.07; 1536 B: 2 -> 6.33, 3 -> 7.07, 4 -> 6.95; 2064 B: 1 -> 4.94,
+// 2 -> 6.69; 2800 B: 1 -> 6.25, 2 -> 6.97.  So up to three choices per units-per-lane count, picked by the row's width.
 #ifndef DEWI_ANY_RSHORT
-#define DEWI_ANY_RSHORT 4
+#define DEWI_ANY_RSHORT 8
 #endif
-constexpr int any_rows(int u, int nq) {
-  if (u == 1) return DEWI_ANY_R1;
-  if (u == 2) return DEWI_ANY_R2;
-  if (u == 3 && nq >= 4) return 2;   // four queries behind every row: two rows in flight (scan_rows_f32's finding)
+constexpr int kAnyLevels = 3;
+constexpr int any_level(int units) {            // 0: the narrowest rows of a units-per-lane count ... 2: the widest
+  const int u = (units + 63) / 64;
+  if (u == 1) return units <= 40 ? 0 : 1;                        // 528-640 B : 656-1024 B
+  if (u == 2) return units <= 72 ? 0 : (units <= 96 ? 1 : 2);    // 1040-1152 B : 1168-1536 B : 1552-2048 B
+  if (u == 4) return units <= 224 ? 0 : 1;                       // 3088-3584 B : 3600-4096 B
+  return 1;
+}
+constexpr int any_rows(int u, int nq, int level) {
+  if (nq >= 4) {                     // four queries behind every row: the arithmetic hides more of the latency
+    if (u == 1) return level == 0 ? 6 : 4;
+    if (u <= 3) return 2;
+    return 1;
+  }
+  if (u == 1) return level == 0 ? 12 : 8;
+  if (u == 2) return level == 0 ? 6 : (level == 1 ? 4 : 3);
+  if (u == 3) return 2;
+  if (u == 4) return level == 0 ? 2 : 1;
   return 1;
 }
 constexpr int kAnyShortRows = DEWI_ANY_RSHORT;   // loads (of 64 / P rows each) a wave of the short-row kernel keeps in flight
@@ -104,12 +117,11 @@ constexpr int kAnyShortRows = DEWI_ANY_RSHORT;   // loads (of 64 / P rows each) 
 // 33 .. 64 U units per row
 // ---------------------------------------------------------------------------------------------
 template <int ELEM, int U, int R, int NQ, int SPACE, int S>
-__global__ __launch_bounds__(kScanThreads) void scan_rows_any(const u32x4* __restrict__ E, int64_t n_rows, int units,
-                                                              const float* __restrict__ Q, int n_candidates,
-                                                              uint64_t* __restrict__ keys, int64_t keys_per_query) {
+__device__ __forceinline__ void scan_rows_any_body(const u32x4* __restrict__ E, int64_t n_rows, int units,
+                                                   const float* __restrict__ Q, int n_candidates,
+                                                   uint64_t* __restrict__ keys, int64_t keys_per_query, MergeShared& merge_buf) {
   constexpr int kCols = ELEM ? 8 : 4;
   constexpr bool DENSE = S == 0;
-  __shared__ MergeShared merge_buf;
   const int lane = lane_id();
   const int wave_in_block = static_cast<int>(threadIdx.x) >> 6;
   const int64_t gwave = static_cast<int64_t>(blockIdx.x) * (kScanThreads / kWave) + wave_in_block;
@@ -199,6 +211,29 @@ __global__ __launch_bounds__(kScanThreads) void scan_rows_any(const u32x4* __res
   }
 }
 
+template <int ELEM, int U, int R, int NQ, int SPACE, int S>
+__global__ __launch_bounds__(kScanThreads) void scan_rows_any(const u32x4* __restrict__ E, int64_t n_rows, int units,
+                                                              const float* __restrict__ Q, int n_candidates,
+                                                              uint64_t* __restrict__ keys, int64_t keys_per_query) {
+  __shared__ MergeShared merge_buf;
+  scan_rows_any_body<ELEM, U, R, NQ, SPACE, S>(E, n_rows, units, Q, n_candidates, keys, keys_per_query, merge_buf);
+}
+
+// REPAIR form: every flagged query of a batch, one corpus pass each, in one launch (knn_scan.hip scan_rows_f32_flagged)
+template <int ELEM, int U, int R, int SPACE, int S>
+__global__ __launch_bounds__(kScanThreads) void scan_rows_any_flagged(const u32x4* __restrict__ E, int64_t n_rows, int units,
+                                                                      const float* __restrict__ Q, int n_candidates,
+                                                                      uint64_t* __restrict__ keys, int64_t keys_per_query,
+                                                                      const uint32_t* __restrict__ flags, int n_queries) {
+  __shared__ MergeShared merge_buf;
+  const int dim = units * (ELEM ? 8 : 4);
+  for (int q = 0; q < n_queries; ++q) {
+    if (flags[q] == 0u) continue;   // wave-uniform
+    scan_rows_any_body<ELEM, U, R, 1, SPACE, S>(E, n_rows, units, Q + static_cast<int64_t>(q) * dim, n_candidates,
+                                                keys + static_cast<int64_t>(q) * keys_per_query, keys_per_query, merge_buf);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // 1 .. 32 units per row: P = 2^log2p lanes per row
 // ---------------------------------------------------------------------------------------------
@@ -216,12 +251,12 @@ __device__ __forceinline__ float group_sum_f32(float v, int log2p) {
 }
 
 template <int ELEM, int R, int NQ, int SPACE, int S>
-__global__ __launch_bounds__(kScanThreads) void scan_short_rows_any(const u32x4* __restrict__ E, int64_t n_rows, int units,
-                                                                    int log2p, const float* __restrict__ Q, int n_candidates,
-                                                                    uint64_t* __restrict__ keys, int64_t keys_per_query) {
+__device__ __forceinline__ void scan_short_rows_any_body(const u32x4* __restrict__ E, int64_t n_rows, int units, int log2p,
+                                                         const float* __restrict__ Q, int n_candidates,
+                                                         uint64_t* __restrict__ keys, int64_t keys_per_query,
+                                                         MergeShared& merge_buf) {
   constexpr int kCols = ELEM ? 8 : 4;
   constexpr bool DENSE = S == 0;
-  __shared__ MergeShared merge_buf;
   const int lane = lane_id();
   const int wave_in_block = static_cast<int>(threadIdx.x) >> 6;
   const int64_t gwave = static_cast<int64_t>(blockIdx.x) * (kScanThreads / kWave) + wave_in_block;
@@ -301,17 +336,48 @@ __global__ __launch_bounds__(kScanThreads) void scan_short_rows_any(const u32x4*
   }
 }
 
+template <int ELEM, int R, int NQ, int SPACE, int S>
+__global__ __launch_bounds__(kScanThreads) void scan_short_rows_any(const u32x4* __restrict__ E, int64_t n_rows, int units,
+                                                                    int log2p, const float* __restrict__ Q, int n_candidates,
+                                                                    uint64_t* __restrict__ keys, int64_t keys_per_query) {
+  __shared__ MergeShared merge_buf;
+  scan_short_rows_any_body<ELEM, R, NQ, SPACE, S>(E, n_rows, units, log2p, Q, n_candidates, keys, keys_per_query, merge_buf);
+}
+
+template <int ELEM, int R, int SPACE, int S>
+__global__ __launch_bounds__(kScanThreads) void scan_short_rows_any_flagged(const u32x4* __restrict__ E, int64_t n_rows, int units,
+                                                                            int log2p, const float* __restrict__ Q,
+                                                                            int n_candidates, uint64_t* __restrict__ keys,
+                                                                            int64_t keys_per_query,
+                                                                            const uint32_t* __restrict__ flags, int n_queries) {
+  __shared__ MergeShared merge_buf;
+  const int dim = units * (ELEM ? 8 : 4);
+  for (int q = 0; q < n_queries; ++q) {
+    if (flags[q] == 0u) continue;   // wave-uniform
+    scan_short_rows_any_body<ELEM, R, 1, SPACE, S>(E, n_rows, units, log2p, Q + static_cast<int64_t>(q) * dim, n_candidates,
+                                                   keys + static_cast<int64_t>(q) * keys_per_query, keys_per_query, merge_buf);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // dispatch (one translation unit per element type instantiates it: knn_scan_any_f32.hip, knn_scan_any_bf16.hip)
 // ---------------------------------------------------------------------------------------------
 template <int ELEM, int NQ, int SPACE, int S>
 static hipError_t launch_any_long(const ScanPlan& plan, const u32x4* E, int64_t n_rows, const float* Q, int c, uint64_t* keys,
                                   hipStream_t stream) {
-#define DEWI_ANY_CASE(UU)                                                                                                   \
-  case UU:                                                                                                                  \
-    hipLaunchKernelGGL((scan_rows_any<ELEM, UU, any_rows(UU, NQ), NQ, SPACE, S>), dim3(plan.blocks), dim3(kScanThreads), 0, \
-                       stream, E, n_rows, plan.units, Q, c, keys, plan.keys_per_query);                                     \
-    return hipGetLastError();
+#define DEWI_ANY_LAUNCH(UU, RR)                                                                                          \
+  hipLaunchKernelGGL((scan_rows_any<ELEM, UU, RR, NQ, SPACE, S>), dim3(plan.blocks), dim3(kScanThreads), 0, stream, E, n_rows, \
+                     plan.units, Q, c, keys, plan.keys_per_query);                                                      \
+  return hipGetLastError();
+#define DEWI_ANY_CASE(UU)                                                                                       \
+  case UU:                                                                                                      \
+    if constexpr (any_rows(UU, NQ, 0) != any_rows(UU, NQ, 1)) {                                                 \
+      if (plan.level == 0) { DEWI_ANY_LAUNCH(UU, any_rows(UU, NQ, 0)) }                                         \
+    }                                                                                                           \
+    if constexpr (any_rows(UU, NQ, 2) != any_rows(UU, NQ, 1)) {                                                 \
+      if (plan.level == 2) { DEWI_ANY_LAUNCH(UU, any_rows(UU, NQ, 2)) }                                         \
+    }                                                                                                           \
+    DEWI_ANY_LAUNCH(UU, any_rows(UU, NQ, 1))
   if constexpr (NQ == 1 || NQ == 4) {
     switch (plan.u_pad) {
       DEWI_ANY_CASE(1)
@@ -332,6 +398,7 @@ static hipError_t launch_any_long(const ScanPlan& plan, const u32x4* E, int64_t 
       default: break;
     }
   }
+#undef DEWI_ANY_LAUNCH
 #undef DEWI_ANY_CASE
   return hipErrorInvalidValue;
 }
@@ -379,6 +446,49 @@ static hipError_t launch_scan_any_impl(const ScanPlan& plan, const void* d_E, in
 #undef DEWI_ANY_Q
 #undef DEWI_ANY_S
   return hipErrorInvalidValue;
+}
+
+// flagged (repair) launches: the middle rows-in-flight level, rows of at most 192 units (see scan_flagged_supported)
+template <int ELEM, int SPACE, int S>
+static hipError_t launch_any_flagged_s(const ScanPlan& plan, const u32x4* E, int64_t n_rows, const float* Q, int n_queries, int c,
+                                       uint64_t* keys, const uint32_t* flags, hipStream_t stream) {
+  if (plan.kind == kScanAnyShort) {
+    hipLaunchKernelGGL((scan_short_rows_any_flagged<ELEM, kAnyShortRows, SPACE, S>), dim3(plan.blocks), dim3(kScanThreads), 0, stream,
+                       E, n_rows, plan.units, plan.log2p, Q, c, keys, plan.keys_per_query, flags, n_queries);
+    return hipGetLastError();
+  }
+#define DEWI_ANY_FLAGGED(UU)                                                                                                     \
+  case UU:                                                                                                                       \
+    hipLaunchKernelGGL((scan_rows_any_flagged<ELEM, UU, any_rows(UU, 1, 1), SPACE, S>), dim3(plan.blocks), dim3(kScanThreads), 0,  \
+                       stream, E, n_rows, plan.units, Q, c, keys, plan.keys_per_query, flags, n_queries);                         \
+    return hipGetLastError();
+  switch (plan.u_pad) {
+    DEWI_ANY_FLAGGED(1)
+    DEWI_ANY_FLAGGED(2)
+    DEWI_ANY_FLAGGED(3)
+    default: break;
+  }
+#undef DEWI_ANY_FLAGGED
+  return hipErrorInvalidValue;
+}
+
+template <int ELEM>
+static hipError_t launch_scan_any_flagged_impl(const ScanPlan& plan, const void* d_E, int64_t n_rows, const float* d_q_raw,
+                                               int n_queries, int n_candidates, int space, uint64_t* d_keys,
+                                               const uint32_t* d_flags, hipStream_t stream) {
+  const u32x4* E = static_cast<const u32x4*>(d_E);
+#define DEWI_ANY_FS(SPACE)                                                                                                         \
+  switch (plan.slots) {                                                                                                            \
+    case 0: return launch_any_flagged_s<ELEM, SPACE, 0>(plan, E, n_rows, d_q_raw, n_queries, n_candidates, d_keys, d_flags, stream); \
+    case 1: return launch_any_flagged_s<ELEM, SPACE, 1>(plan, E, n_rows, d_q_raw, n_queries, n_candidates, d_keys, d_flags, stream); \
+    default: return launch_any_flagged_s<ELEM, SPACE, kMaxSlots>(plan, E, n_rows, d_q_raw, n_queries, n_candidates, d_keys, d_flags, stream); \
+  }
+  if (space == DEWI_SPACE_COSINE) {
+    DEWI_ANY_FS(DEWI_SPACE_COSINE)
+  } else {
+    DEWI_ANY_FS(DEWI_SPACE_L2)
+  }
+#undef DEWI_ANY_FS
 }
 
 }  // namespace dewi

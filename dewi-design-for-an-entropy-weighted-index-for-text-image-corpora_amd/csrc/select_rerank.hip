@@ -6,6 +6,8 @@
 //   argpartition(adj, -k)[-k:], argsort(-adj)              -> bitonic sort in LDS, first k
 // One workgroup per query.  The work is O(keys) with keys << corpus bytes; this kernel is
 // latency-bound, not bandwidth-bound, and is kept to a handful of passes over L2-resident keys.
+#include <stdlib.h>
+
 #include "select_common.hpp"
 
 namespace dewi {
@@ -569,13 +571,23 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(
     const uint64_t* __restrict__ keys_all, int64_t keys_per_query, int sorted_lists, int n_candidates, int k,
     RerankParams rp, const float* __restrict__ dewi32, const float* __restrict__ ent32, int64_t id_offset,
     int64_t* __restrict__ out_ids, float* __restrict__ out_scores, dewi_candidate* __restrict__ out_cand,
-    const uint32_t* __restrict__ counts, SegmentLayout seg, RefineParams refine) {
+    const uint32_t* __restrict__ counts, SegmentLayout seg, RefineParams refine, QueryFlags flags) {
   __shared__ SelectShared sh;
   const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
   const int q = static_cast<int>(blockIdx.x);
   const uint64_t* keys = keys_all + static_cast<int64_t>(q) * keys_per_query;
   int n_sel;
-  auto refuse = [&]() {            // ids -1 / records -2: the documented marker of a query the approximate pass could not answer
+  if (flags.mode == 2) {           // repair launch: only the queries the approximate pass refused (block-uniform)
+    if (flags.p[q] == 0u) return;
+  } else if (flags.mode == 1 && tid == 0) {
+    flags.p[q] = 0u;               // (the same thread raises it in refuse(): program order)
+  }
+  auto refuse = [&]() {
+    if (flags.mode == 1) {         // the repair launches behind this one answer the query on the exact row kernels
+      if (tid == 0) flags.p[q] = 1u;
+      return;
+    }
+    // no flags: ids -1 / records -2 mark a query the approximate pass could not answer
     if (out_cand != nullptr) {   // shard mode: every record of this query carries the marker id -2
       for (int j = tid; j < n_candidates; j += nt) {
         dewi_candidate rec;
@@ -686,21 +698,31 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(
         return;
       }
       __syncthreads();
-      // Gather the valid records of the half-segments into LDS once; the radix-select passes then run
-      // over a dense LDS array instead of re-walking global memory five times.
-      if (tid == 0) sh.count = 0;
-      __syncthreads();
-      kv.for_each(tid, nt, [&](uint64_t key) {
-        const uint32_t pos = atomicAdd(&sh.count, 1u);
-        if (pos < static_cast<uint32_t>(seg.lds_keys)) dyn_keys[pos] = key;
-      });
-      __syncthreads();
-      const uint32_t total = sh.count;
-      __syncthreads();
-      if (total <= static_cast<uint32_t>(seg.lds_keys))
-        n_sel = exact_top_candidates(ArrayKeys{dyn_keys, static_cast<int64_t>(total)}, n_candidates, sh);
-      else
-        n_sel = exact_top_candidates(kv, n_candidates, sh);
+      if (refine.E != nullptr) {
+        // more segments than threads (or ordered keys) with the exact refinement on: the scores are approximate here too —
+        // widened cut and exact re-scoring straight from the segments, never the approximate keys as they stand
+        n_sel = refine_from_segments(kv, dyn_keys, n_candidates, sh, refine, q);
+        if (n_sel == -2) {
+          refuse();
+          return;
+        }
+      } else {
+        // Gather the valid records of the half-segments into LDS once; the radix-select passes then run
+        // over a dense LDS array instead of re-walking global memory five times.
+        if (tid == 0) sh.count = 0;
+        __syncthreads();
+        kv.for_each(tid, nt, [&](uint64_t key) {
+          const uint32_t pos = atomicAdd(&sh.count, 1u);
+          if (pos < static_cast<uint32_t>(seg.lds_keys)) dyn_keys[pos] = key;
+        });
+        __syncthreads();
+        const uint32_t total = sh.count;
+        __syncthreads();
+        if (total <= static_cast<uint32_t>(seg.lds_keys))
+          n_sel = exact_top_candidates(ArrayKeys{dyn_keys, static_cast<int64_t>(total)}, n_candidates, sh);
+        else
+          n_sel = exact_top_candidates(kv, n_candidates, sh);
+      }
     }
   } else if (refine.E != nullptr && refine.list_len > 0) {
     extern __shared__ __attribute__((aligned(16))) uint64_t dyn_scratch[];     // kMaxSortCandidates keys (launcher)
@@ -1030,7 +1052,7 @@ hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, 
                                 int n_candidates, int k, const RerankParams& rp, const float* d_dewi32,
                                 const float* d_ent32, int64_t id_offset, int64_t* d_out_ids, float* d_out_scores,
                                 dewi_candidate* d_out_cand, const uint32_t* d_counts, const SegmentLayout& seg,
-                                hipStream_t stream, const RefineParams& refine) {
+                                hipStream_t stream, const RefineParams& refine, const QueryFlags& flags) {
   int threads = kSelectThreads;
   const bool refine_lists = refine.E != nullptr && refine.list_len > 0;   // one query through the shadow on the row kernel
   if (refine_lists) {
@@ -1042,9 +1064,17 @@ hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, 
   } else if (keys_per_query <= 4096 && n_candidates <= 128 && refine.E == nullptr) {
     threads = 256;   // (refine mode re-scores its candidates one wave each: sixteen waves)
   }
+  // DEWI_SELECT_THREADS (tests only, 256 .. 1024): fewer threads than survivor segments puts a matrix-core batch on the
+  // kernel's more-segments-than-threads route
+  static const int threads_override = [] { const char* e = getenv("DEWI_SELECT_THREADS"); return e ? atoi(e) : 0; }();
+  if (d_counts != nullptr && threads_override >= 256 && threads_override <= kSelectThreads && threads_override % kWave == 0)
+    threads = threads_override;
   size_t dyn = refine_lists ? static_cast<size_t>(kMaxSortCandidates) * 8 : 0;     // scratch of the exact re-scoring
   if (d_counts != nullptr && seg.lds_keys > 0) {
-    dyn = static_cast<size_t>(seg.lds_keys) * 8;
+    // the staging limit (seg.lds_keys, which tests shrink) is one thing, the allocation another: the exact re-scoring uses
+    // the dynamic array as scratch for up to kMaxSortCandidates keys whatever was staged
+    const int alloc_keys = (refine.E != nullptr && seg.lds_keys < kMaxSortCandidates) ? kMaxSortCandidates : seg.lds_keys;
+    dyn = static_cast<size_t>(alloc_keys) * 8;
     static PerDeviceOnce attr_once;
     const hipError_t e = attr_once.run([] {
       return hipFuncSetAttribute(reinterpret_cast<const void*>(&select_rerank_kernel),
@@ -1054,7 +1084,7 @@ hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, 
   }
   hipLaunchKernelGGL(select_rerank_kernel, dim3(n_queries), dim3(threads), dyn, stream, d_keys, keys_per_query,
                      sorted_lists, n_candidates, k, rp, d_dewi32, d_ent32, id_offset, d_out_ids, d_out_scores,
-                     d_out_cand, d_counts, seg, refine);
+                     d_out_cand, d_counts, seg, refine, flags);
   return hipGetLastError();
 }
 

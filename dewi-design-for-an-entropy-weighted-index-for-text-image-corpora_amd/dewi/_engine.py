@@ -48,6 +48,7 @@ class DeviceCorpus:
         self.shadow = None            # bf16 copy of an fp32 matrix (enable_bf16_shadow): pre-selection over half the bytes
         self.shadow_min_batch = 2     # smallest batch that goes through the shadow (enable_bf16_shadow(single_query=True): 1)
         self._io: Dict[Tuple[int, int], tuple] = {}      # (batch, k) -> device + pinned result buffers of search()
+        self._last_call = None        # (batch, k, cut, through the shadow, workspace) of the last search_device
         # The blocking search() stages queries and results through per-instance buffers (pinned query, device
         # query, cached result buffers, workspaces): one caller at a time.  The reference's ExactIndex.search is
         # read-only and therefore safe under concurrent callers; this lock keeps that property for a threaded server.
@@ -192,12 +193,9 @@ class DeviceCorpus:
         (hnswlib: 1 - dist) or "inv_one_plus_dist" (faiss L2: 1/(1+dist)) — reference
         backends.py:229-231, 335-338.
 
-        NOT thread-safe on one instance (shared workspaces) and it does not look at the answer: on a
-        bf16 corpus a batch of >= 2 queries takes the matrix-core path, which marks a query whose
-        survivor buffer overflowed (adversarial corpora only) with id -1 / score NaN in every slot.
-        Callers that keep results on the device must check ``unanswered(ids)`` after synchronising
-        and re-run those queries one at a time with ``use_shadow=False`` (a single query then always
-        takes the exact kernels); the blocking ``search`` and ``PipelinedSearcher.drain`` do that.
+        NOT thread-safe on one instance (shared workspaces).  Always answered: a query that a matrix-core pass of
+        the batch refuses (adversarial corpora) is repaired inside the library call, on the same stream (ABI 5) — no
+        id -1 ever reaches the outputs, so there is nothing for the caller to check after synchronising.
         """
         torch = _torch()
         b = int(q_dev.shape[0])
@@ -217,7 +215,9 @@ class DeviceCorpus:
         if candidates is None and similarity != "ip":
             raise ValueError("similarity transforms belong to the ANN re-rank rule: pass candidates=k as well")
         ws = self._workspace(b, max(c, 1))
-        if candidates is None and self.shadow is not None and b >= self.shadow_min_batch and use_shadow:
+        through_shadow = candidates is None and self.shadow is not None and b >= self.shadow_min_batch and use_shadow
+        self._last_call = (b, k, max(c, 1), bool(through_shadow), ws)
+        if through_shadow:
             rc = self._lib.dewi_knn_rerank_f32_shadow(
                 nat.ptr(self.emb), nat.ptr(self.shadow), self.n_rows, self.dim, nat.ptr(q_dev), b, nat.ptr(self.dewi32),
                 nat.ptr(self.ent32), k, float(eta), float(entropy_pref), nat.SPACE_CODES[self.space], nat.ptr(out_ids),
@@ -235,26 +235,29 @@ class DeviceCorpus:
         nat.check(rc)
         return out_ids, out_scores
 
-    @staticmethod
-    def unanswered(ids_host: np.ndarray) -> np.ndarray:
-        """Indices of the queries a batched matrix-core pass refused (id -1 in slot 0)."""
-        if ids_host.size == 0:
-            return np.empty(0, dtype=np.int64)
-        return np.nonzero(ids_host[:, 0] < 0)[0]
-
-    def repair_unanswered(self, q_dev, ids_host: np.ndarray, scores_host: np.ndarray, k: int, eta: float,
-                          entropy_pref: float, candidates: Optional[int] = None, similarity: str = "ip") -> int:
-        """Re-run every refused query of a finished batch alone (exact small-batch kernels) and patch
-        the host arrays in place (local row ids).  Returns how many were repaired."""
+    def refused_by_last_call(self) -> np.ndarray:
+        """Monitoring / tests: bool [B] — which queries of the LAST ``search_device`` call a matrix-core pass refused (and the
+        repair launches inside the same library call answered).  All False for a shape that takes the row kernels.
+        Synchronises the current stream."""
         torch = _torch()
-        redo = self.unanswered(ids_host)
-        for j in redo.tolist():
-            sub = q_dev[j:j + 1].contiguous()
-            i2, s2 = self.search_device(sub, k, eta, entropy_pref, candidates=candidates, similarity=similarity,
-                                        use_shadow=False)
-            ids_host[j] = i2.cpu().numpy()[0]
-            scores_host[j] = s2.cpu().numpy()[0]
-        return int(len(redo))
+        b, k, c, through_shadow, ws = self._last_call
+        off = ctypes.c_size_t(0)
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.dewi_knn_refusal_flags(1 if self.is_bf16 else 0, 1 if through_shadow else 0, self.n_rows, self.dim,
+                                                       b, k, c, nat.SPACE_CODES[self.space], ctypes.byref(off)))
+            torch.cuda.current_stream().synchronize()
+        if off.value == ctypes.c_size_t(-1).value:
+            return np.zeros(b, dtype=bool)
+        return ws[off.value: off.value + 4 * b].view(torch.int32).cpu().numpy() != 0
+
+    def scan_kernel_name(self, n_queries: int, k: int, candidates: Optional[int] = None) -> str:
+        """The kernel that streams the corpus for a batch of this size (``dewi_knn_scan_kernel``): measurement label."""
+        c = min(2 * int(k), self.n_rows) if candidates is None else min(int(candidates), self.n_rows)
+        buf = ctypes.create_string_buffer(128)
+        with _torch().cuda.device(self.device):
+            nat.check(self._lib.dewi_knn_scan_kernel(1 if self.is_bf16 else 0, self.n_rows, self.dim, int(n_queries), max(c, 1),
+                                                     nat.SPACE_CODES[self.space], buf, 128))
+        return buf.value.decode()
 
     def search(self, queries: ArrayLike, k: int = 10, eta: float = 0.5, entropy_pref: float = 0.0,
                candidates: Optional[int] = None, similarity: str = "ip") -> Tuple[np.ndarray, np.ndarray]:
@@ -284,11 +287,7 @@ class DeviceCorpus:
                 torch.cuda.current_stream().synchronize()
             ids_h = io[2].numpy().copy()
             scores_h = io[3].numpy().copy()
-            # The batched bf16 matrix-core path marks a query whose candidate buffer overflowed
-            # (adversarial corpora, e.g. tens of thousands of duplicates of a top document) with
-            # id -1: such queries are answered again by the exact small-batch kernels.
-            if kk > 0:
-                self.repair_unanswered(q, ids_h, scores_h, k, eta, entropy_pref, candidates, similarity)
+            # (a query a matrix-core pass refused was repaired inside the library call, on the stream: ABI 5)
         if self.id_offset:
             ids_h = ids_h + self.id_offset
         return ids_h, scores_h
@@ -301,6 +300,7 @@ class DeviceCorpus:
             out = torch.empty((b, n_candidates, 4), dtype=torch.int32, device=self.device)
         c_local = max(1, min(n_candidates, self.n_rows))
         ws = self._workspace(b, c_local)
+        self._last_call = (b, max(1, c_local // 2), c_local, False, ws)
         rc = self._lib.dewi_knn_candidates(nat.ptr(self.emb), 1 if self.is_bf16 else 0, self.n_rows, self.dim,
                                            nat.ptr(q_dev), b, nat.ptr(self.dewi32), nat.ptr(self.ent32),
                                            int(n_candidates), nat.SPACE_CODES[self.space], self.id_offset, nat.ptr(out),
@@ -319,14 +319,10 @@ class PipelinedSearcher:
     reading the outputs.
 
     ``dewi_knn_scan`` / ``dewi_knn_finish`` take the same kernels as the one-call search (a batch of
-    queries: the matrix-core passes), so a query of a batch can come back refused (id -1, survivor
-    buffer overflowed: adversarial corpora only).  ``drain`` looks at the id output of the last
-    submission into each output buffer (an earlier submission into the same buffer has been overwritten anyway) and
-    answers such queries again one at a time, in place, with the shard's ``id_offset`` as ``dewi_knn_finish`` writes
-    it — from the query tensor that was SUBMITTED, which is kept by reference: a caller that reuses one staging buffer
-    for its queries must not overwrite it before ``drain`` (or must submit a clone);
-    candidate records (``out_records``) keep their -2 markers for the merge, as
-    ``DeviceCorpus.candidates_device``.  The workspace size and the path are fixed from the
+    queries: the matrix-core passes); a query such a pass refuses is repaired by ``dewi_knn_finish`` itself
+    (ABI 5), from the query tensor that was SUBMITTED — which must therefore stay untouched until the finish
+    step has run (``drain``, or an event on ``finish_stream``): a caller that reuses one staging buffer for
+    its queries submits a clone.  The workspace size and the path are fixed from the
     submitting thread's tuning (``_engine.tuning`` is thread-local): construct and submit from one thread.
     """
 
@@ -354,8 +350,6 @@ class PipelinedSearcher:
             self._scan_done = [torch.cuda.Event() for _ in range(self.depth)]
             self._finish_done = [torch.cuda.Event() for _ in range(self.depth)]
         self._i = 0
-        self._explicit_c = n_candidates is not None
-        self._written = {}            # id-output buffer -> (queries, ids, scores) of the last batch written there
         self._elem = 1 if corpus.is_bf16 else 0
         self._space = nat.SPACE_CODES[corpus.space]
         self._emb, self._dewi, self._ent = nat.ptr(corpus.emb), nat.ptr(corpus.dewi32), nat.ptr(corpus.ent32)
@@ -380,15 +374,13 @@ class PipelinedSearcher:
         self._scan_done[slot].record(scan_stream)
         self.finish_stream.wait_event(self._scan_done[slot])
         if out_records is None:
-            rc = self._lib.dewi_knn_finish(self._ws[slot].data_ptr(), self._need, self._emb, self._elem, c.n_rows, c.dim, self.b,
-                                           self.c, self._space, self.k, self.eta, self.pref, self._dewi, self._ent, c.id_offset,
-                                           out_ids.data_ptr(), out_scores.data_ptr(), 0, self._s_fin)
-            if self.b >= 2:
-                self._written[out_ids.data_ptr()] = (q_dev, out_ids, out_scores)
+            rc = self._lib.dewi_knn_finish(self._ws[slot].data_ptr(), self._need, self._emb, self._elem, c.n_rows, c.dim,
+                                           q_dev.data_ptr(), self.b, self.c, self._space, self.k, self.eta, self.pref, self._dewi,
+                                           self._ent, c.id_offset, out_ids.data_ptr(), out_scores.data_ptr(), 0, self._s_fin)
         else:
-            rc = self._lib.dewi_knn_finish(self._ws[slot].data_ptr(), self._need, self._emb, self._elem, c.n_rows, c.dim, self.b,
-                                           self.c, self._space, 0, 0.0, 0.0, self._dewi, self._ent, c.id_offset, 0, 0,
-                                           out_records.data_ptr(), self._s_fin)
+            rc = self._lib.dewi_knn_finish(self._ws[slot].data_ptr(), self._need, self._emb, self._elem, c.n_rows, c.dim,
+                                           q_dev.data_ptr(), self.b, self.c, self._space, 0, 0.0, 0.0, self._dewi, self._ent,
+                                           c.id_offset, 0, 0, out_records.data_ptr(), self._s_fin)
         if rc:
             nat.check(rc)
         self._finish_done[slot].record(self.finish_stream)
@@ -397,22 +389,6 @@ class PipelinedSearcher:
         for st in self._scan_streams:
             st.synchronize()
         self.finish_stream.synchronize()
-        if not self._written:
-            return
-        torch = _torch()
-        written, self._written = self._written, {}
-        with torch.cuda.device(self.corpus.device):
-            for q_dev, out_ids, out_scores in written.values():
-                if out_ids.numel() == 0:
-                    continue
-                for j in torch.nonzero(out_ids.view(self.b, -1)[:, 0] < 0).flatten().tolist():   # refused by a matrix-core pass
-                    row_ids = out_ids.view(self.b, -1)[j:j + 1]
-                    self.corpus.search_device(q_dev[j:j + 1].contiguous(), self.k, self.eta, self.pref,
-                                              row_ids, out_scores.view(self.b, -1)[j:j + 1],
-                                              candidates=self.c if self._explicit_c else None, use_shadow=False)
-                    if self.corpus.id_offset:          # dewi_knn_finish wrote the other rows with the shard's id offset;
-                        row_ids += self.corpus.id_offset   # the one-call search answers in local rows
-            torch.cuda.current_stream().synchronize()
 
 
 _merge_ws: Dict[object, "torch.Tensor"] = {}      # per device: scratch of the large merge (stream-ordered reuse)

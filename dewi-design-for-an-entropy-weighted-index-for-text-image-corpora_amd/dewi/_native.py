@@ -31,12 +31,12 @@ MODE_CODES = {"standard": 0, "conditional": 1}
 #: similarity the ANN-semantics re-rank blends (include/dewi_hip.h DEWI_SIM_*; reference backends.py:229-231, 335-338)
 SIM_CODES = {"ip": 0, "one_minus_dist": 1, "inv_one_plus_dist": 2}
 NUM_SIGNALS = 7
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 #: every symbol include/dewi_hip.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = (
     "dewi_abi_version", "dewi_last_error", "dewi_device_info", "dewi_normalize_rows_f32",
-    "dewi_row_cosine_f32", "dewi_convert_f32_to_bf16", "dewi_payload_soa_f64", "dewi_knn_workspace_bytes", "dewi_knn_rerank_f32", "dewi_knn_rerank_f32_shadow",
+    "dewi_row_cosine_f32", "dewi_convert_f32_to_bf16", "dewi_payload_soa_f64", "dewi_knn_workspace_bytes", "dewi_knn_scan_kernel", "dewi_knn_refusal_flags", "dewi_knn_rerank_f32", "dewi_knn_rerank_f32_shadow",
     "dewi_knn_rerank_bf16", "dewi_knn_rerank_candidates", "dewi_prepare_queries_bf16", "dewi_knn_scan", "dewi_knn_finish", "dewi_knn_candidates", "dewi_merge_workspace_bytes", "dewi_merge_rerank", "dewi_robust_fit_workspace_bytes",
     "dewi_robust_fit_f32", "dewi_robust_fit_begin", "dewi_robust_fit_hist_f32", "dewi_robust_fit_region",
     "dewi_robust_fit_pick", "dewi_robust_fit_finish", "dewi_score_f64", "dewi_score_f64_dev", "dewi_timing_enable", "dewi_timing_read", "dewi_tuning_set",
@@ -86,7 +86,11 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.dewi_knn_scan.restype = i32
     lib.dewi_knn_scan.argtypes = [vp, i32, i64, i32, vp, i32, i32, i32, vp, sz, vp]
     lib.dewi_knn_finish.restype = i32
-    lib.dewi_knn_finish.argtypes = [vp, sz, vp, i32, i64, i32, i32, i32, i32, i32, f64, f64, vp, vp, i64, vp, vp, vp, vp]
+    lib.dewi_knn_finish.argtypes = [vp, sz, vp, i32, i64, i32, vp, i32, i32, i32, i32, f64, f64, vp, vp, i64, vp, vp, vp, vp]
+    lib.dewi_knn_refusal_flags.restype = i32
+    lib.dewi_knn_refusal_flags.argtypes = [i32, i32, i64, i32, i32, i32, i32, i32, c.POINTER(sz)]
+    lib.dewi_knn_scan_kernel.restype = i32
+    lib.dewi_knn_scan_kernel.argtypes = [i32, i64, i32, i32, i32, i32, c.c_char_p, sz]
     lib.dewi_knn_candidates.restype = i32
     lib.dewi_knn_candidates.argtypes = [vp, i32, i64, i32, vp, i32, vp, vp, i32, i32, i64, vp, vp, sz, vp]
     lib.dewi_merge_rerank.restype = i32

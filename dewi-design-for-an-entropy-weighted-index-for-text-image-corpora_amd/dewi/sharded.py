@@ -117,17 +117,9 @@ class ShardedSearcher:
             ids, scores = self._merge(lists, c, k, float(eta), float(entropy_pref))
             return to_np(ids), to_np(scores)
 
-        ids, scores = one_pass(queries)
-        # A bf16 shard's batched matrix-core path marks a query whose survivor buffer overflowed
-        # (adversarial corpora); the merge then returns id -1 for it on EVERY rank, so all ranks agree on
-        # the retry: that query alone (batch 1 takes the exact small-batch kernels).
-        unanswered = np.nonzero(ids[:, 0] < 0)[0]
-        if len(unanswered):
-            ids, scores = ids.copy(), scores.copy()
-            q2 = np.atleast_2d(to_np(queries))
-            for b in unanswered:
-                ids[b], scores[b] = (a[0] for a in one_pass(q2[b:b + 1]))
-        return ids, scores
+        # (a query a shard's matrix-core pass refuses is repaired inside that shard's dewi_knn_candidates / dewi_knn_finish:
+        # every record that reaches the exchange is real or padding, ABI 5)
+        return one_pass(queries)
 
 
 def build_local_shard(rows: np.ndarray, dewi: Sequence[float], ht_mean: Sequence[float], hi_mean: Sequence[float],

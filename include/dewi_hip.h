@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DEWI_ABI_VERSION 4
+#define DEWI_ABI_VERSION 5
 
 /* status codes */
 #define DEWI_OK 0
@@ -111,8 +111,22 @@ int dewi_payload_soa_f64(const double* d_dewi, const double* d_ht_mean, const do
  * d_out_ids [n_queries][k] int64 row indices, d_out_scores [n_queries][k] fp32.
  * k <= 0 writes nothing and returns DEWI_OK (reference returns []); k > n_rows returns
  * DEWI_ERR_K_OUT_OF_BOUNDS (reference: ValueError from np.argpartition).
+ *
+ * ALWAYS ANSWERED (ABI 5), as ExactIndex.search is (backends.py:414-481): batches run on matrix-core passes that can
+ * refuse a query on adversarial corpora (a survivor segment overflowed; more rows inside an error band than the sort
+ * holds).  Every entry point that may take such a pass — dewi_knn_rerank_f32 / _bf16 / _f32_shadow / _candidates,
+ * dewi_knn_finish, dewi_knn_candidates — enqueues, behind the pass's select and on the same stream, two fixed-shape
+ * REPAIR launches that read the per-query refusal flags from the workspace and answer the flagged queries on the
+ * exact row kernels (they return at once when no flag is set).  No id -1 / -2 marker ever reaches the caller.
  * ------------------------------------------------------------------------------------------ */
 size_t dewi_knn_workspace_bytes(int64_t n_rows, int dim, int n_queries, int n_candidates);
+
+/* Name of the kernel that streams the corpus for this shape on the calling thread's current device and tuning, as
+ * rocprofv3 prints it up to its template arguments ("scan_rows_f32", "scan_rows_any<0, 2, 3, 1, 0, 1>",
+ * "scan_short_rows_any<0, 8, 1, 0, 1>", "scan_generic_f32", "mfma_scan_f32<false", "mfma_scan_bf16_s16"): what a
+ * measurement harness labels its roofline line with.  (ABI 5.) */
+int dewi_knn_scan_kernel(int elem_type, int64_t n_rows, int dim, int n_queries, int n_candidates, int space, char* out,
+                         size_t out_bytes);
 
 int dewi_knn_rerank_f32(const float* d_E, int64_t n_rows, int dim, const float* d_Q, int n_queries,
                         const float* d_dewi32, const float* d_ent32, int k, double eta, double entropy_pref,
@@ -129,11 +143,20 @@ int dewi_knn_rerank_f32(const float* d_E, int64_t n_rows, int dim, const float* 
  * equal dewi_knn_rerank_f32's one-query results bit for bit.  The bound assumes STORED rows of norm <= 1.0001 (what
  * dewi_normalize_rows_f32 leaves; the host layer checks it once).  Cosine, dim 256 / 512 / 768 / 1024 / 1536, corpus >= 64 K rows;
  * any other call (and d_E_bf16 == NULL) behaves exactly as dewi_knn_rerank_f32.  A query with more candidates inside
- * the error band than the sort holds comes back refused (id -1) like any matrix-core batch.  (ABI 4.) */
+ * the error band than the sort holds is answered by the repair launches on the plain fp32 scan (ABI 5; ABI 4 returned
+ * it refused, id -1).  (ABI 4.) */
 int dewi_knn_rerank_f32_shadow(const float* d_E, const uint16_t* d_E_bf16, int64_t n_rows, int dim, const float* d_Q,
                                int n_queries, const float* d_dewi32, const float* d_ent32, int k, double eta,
                                double entropy_pref, int space, int64_t* d_out_ids, float* d_out_scores,
                                void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* Monitoring / tests: where in the workspace the per-query refusal flags of such a call live (one uint32 per query: 1 =
+ * the matrix-core pass refused the query and the repair launches answered it; valid once the call's work on the stream
+ * has finished).  *out_offset_bytes = (size_t)-1 when the shape takes the row kernels, which refuse nothing.
+ * through_shadow: the call is dewi_knn_rerank_f32_shadow with a shadow; n_candidates <= 0: the default cut min(2k, n_rows).
+ * (ABI 5.) */
+int dewi_knn_refusal_flags(int elem_type, int through_shadow, int64_t n_rows, int dim, int n_queries, int k, int n_candidates,
+                           int space, size_t* out_offset_bytes);
 
 /* A10 / F4  the same search with an explicit candidate count instead of min(2k, n_rows): n_candidates =
  * k reproduces the re-rank rule of the reference's HNSWIndex / FAISSIndex.search (backends.py:204-241,
@@ -158,8 +181,9 @@ int dewi_prepare_queries_bf16(const float* d_Q, int n_queries, int dim, int spac
  * workspace) and dewi_knn_finish steps 3b-5 (select, blend, top-k) from that workspace.  The two may be
  * enqueued on DIFFERENT streams (order them with events) so that the finish of batch i overlaps the scan of
  * batch i+1 on a second workspace; dewi_knn_rerank_* == scan + finish on one stream, on the same kernels: a
- * batch takes the same path (row kernels / matrix-core passes) either way, so a query of a matrix-core batch
- * whose survivor buffer overflowed comes back marked (id -1; records: id -2) here too.
+ * batch takes the same path (row kernels / matrix-core passes) either way; the repair of a refused query
+ * (see "always answered" above) is part of dewi_knn_finish, which therefore takes the RAW queries d_Q that
+ * dewi_knn_scan was given (ABI 5).
  * dewi_knn_finish writes final results (d_out_cand == NULL) or, for doc-id shards, the shard's
  * `n_candidates` best rows as dewi_candidate records (d_out_cand != NULL; d_out_ids/scores unused,
  * k ignored), exactly as dewi_knn_candidates.  elem_type/n_rows/dim/n_queries/n_candidates/space must equal
@@ -171,7 +195,7 @@ int dewi_knn_scan(const void* d_E, int elem_type, int64_t n_rows, int dim, const
                   int n_candidates, int space, void* d_workspace, size_t workspace_bytes, void* stream);
 
 int dewi_knn_finish(void* d_workspace, size_t workspace_bytes, const void* d_E, int elem_type, int64_t n_rows, int dim,
-                    int n_queries, int n_candidates, int space, int k, double eta, double entropy_pref,
+                    const float* d_Q, int n_queries, int n_candidates, int space, int k, double eta, double entropy_pref,
                     const float* d_dewi32, const float* d_ent32, int64_t id_offset, int64_t* d_out_ids,
                     float* d_out_scores, dewi_candidate* d_out_cand, void* stream);
 
@@ -189,8 +213,8 @@ int dewi_knn_rerank_bf16(const uint16_t* d_E, int64_t n_rows, int dim, const flo
  * `id_offset` is added to the local row index.  d_out [n_queries][n_candidates].
  * elem_type: 0 = fp32 corpus, 1 = bf16 corpus.  A bf16 shard with >= 2 queries takes the batched
  * matrix-core path (same conditions as dewi_knn_rerank_bf16); a query whose survivor buffer
- * overflowed there is NOT answered and all its records carry id = -2 (sim NaN): dewi_merge_rerank
- * then returns id -1 for that query and the caller re-runs it alone (a single query always takes the exact small-batch kernels).
+ * overflowed there is answered by the repair launches (ABI 5), so every record is real or padding.
+ * (dewi_merge_rerank still maps an id -2 record — an ABI-4 shard — to id -1 for its query.)
  * ------------------------------------------------------------------------------------------ */
 int dewi_knn_candidates(const void* d_E, int elem_type, int64_t n_rows, int dim, const float* d_Q,
                         int n_queries, const float* d_dewi32, const float* d_ent32, int n_candidates,

@@ -26,7 +26,7 @@ ap.add_argument("--seed", type=int, default=1)
 args = ap.parse_args()
 rs = np.random.RandomState(args.seed)
 t_end = time.time() + args.seconds
-n_corp = n_q = n_refused = n_rows_route = 0
+n_corp = n_q = n_refused = n_rows_route = n_host_repairs = 0
 fails = []
 while time.time() < t_end:
     dim = int(rs.choice([256, 512, 768, 1024, 1536]))
@@ -52,9 +52,12 @@ while time.time() < t_end:
         eta = float(rs.choice([0.0, 0.3, 0.7, 1.0]))
         pref = float(rs.choice([0.0, 0.2, -0.5]))
         n_rows_route += k <= 16
-        raw_ids, _ = sh.search_device(torch.from_numpy(q[None]).cuda(), k, eta, pref)
-        n_refused += int(raw_ids[0, 0] < 0)
-        ids, sc = sh.search(q, k, eta, pref)
+        # the RAW library call (search_device: nothing on the host looks at the answer); a query the pass refuses is
+        # repaired inside it (ABI 5) — refused_by_last_call() reads the flags the pass left in the workspace
+        raw_ids, raw_sc = sh.search_device(torch.from_numpy(q[None]).cuda(), k, eta, pref)
+        n_refused += int(sh.refused_by_last_call()[0])
+        ids, sc = raw_ids.cpu().numpy(), raw_sc.cpu().numpy()
+        n_host_repairs += int(ids[0, 0] < 0)
         i1, s1 = plain.search(q, k, eta, pref)
         n_q += 1
         if not (np.array_equal(ids, i1) and np.array_equal(sc, s1) and ids.min() >= 0):
@@ -62,6 +65,7 @@ while time.time() < t_end:
             fails.append(case)
             print("FAIL", case, ids[0, :5], i1[0, :5], flush=True)
     print(f"[{args.seconds - (t_end - time.time()):5.0f} s] {n_corp} corpora, {n_q} queries ({n_rows_route} on the row-kernel route), "
-          f"{n_refused} raw calls refused and repaired, {len(fails)} failures", flush=True)
-print(f"DONE: {n_corp} corpora, {n_q} queries, {n_refused} refused and repaired, {len(fails)} failures")
+          f"{n_refused} refused by the pass and repaired inside the call, {n_host_repairs} host repairs, {len(fails)} failures", flush=True)
+print(f"DONE: {n_corp} corpora, {n_q} queries, {n_refused} refused by the pass and repaired inside the call, "
+      f"{n_host_repairs} host repairs, {len(fails)} failures")
 sys.exit(1 if fails else 0)

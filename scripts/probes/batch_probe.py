@@ -85,7 +85,7 @@ for b in sizes:
         def scan(i):
             nat.check(lib.dewi_knn_scan(nat.ptr(c.emb), et, n, d, nat.ptr(Q[i % 8]), b, cc, sp, nat.ptr(ws), need, nat.stream_ptr()))
         def fin():
-            nat.check(lib.dewi_knn_finish(nat.ptr(ws), need, nat.ptr(c.emb), et, n, d, b, cc, sp, k, 0.3, 0.0, nat.ptr(c.dewi32), nat.ptr(c.ent32), 0,
+            nat.check(lib.dewi_knn_finish(nat.ptr(ws), need, nat.ptr(c.emb), et, n, d, nat.ptr(Q[0]), b, cc, sp, k, 0.3, 0.0, nat.ptr(c.dewi32), nat.ptr(c.ent32), 0,
                                           nat.ptr(oi), nat.ptr(osc), 0, nat.stream_ptr()))
         for what, fn in (("scan", scan), ("finish", lambda i: fin()), ("scan+finish", lambda i: (scan(i), fin()))):
             for i in range(5):

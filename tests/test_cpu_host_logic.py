@@ -209,7 +209,6 @@ def test_blocking_search_is_serialised_per_corpus():
         return not res[0]
     c.stage_queries = lambda q: (held.append(owned()), torch.zeros((1, 4)))[1]
     c.search_device = lambda *a, **kw: held.append(owned())
-    c.repair_unanswered = lambda *a, **kw: held.append(owned()) or 0
 
     class _NoDev:
         def __enter__(self):

@@ -11,7 +11,7 @@ noise (gap 1e-6) instead of at a bf16 ulp:
   2. the search against the oracle run on THOSE prepared queries and the bf16-rounded corpus:
      products of bf16 values are exact in fp32, so what is left is the accumulation order.
 
-``search_device`` is called (not the blocking ``search``), so a refused query (id -1) would be
+``search_device`` is called (not the blocking ``search``), so an unanswered query (id -1) would be
 seen here, not repaired.  The batched path and the small-batch scan kernels must also agree with
 each other.
 """
@@ -73,9 +73,10 @@ def test_mfma_batched_vs_oracle(dim, n, b, k):
     assert agree > 0.98, agree          # the two paths sum in different orders: rare near-tie swaps only
 
 
-def test_mfma_overflow_falls_back_to_exact_path():
-    """40 000 exact duplicates of the query's best document overflow the candidate buffer of that
-    query (capacity 4*32*c); the marker (-1) triggers the exact small-batch kernels."""
+def test_mfma_overflow_is_repaired_behind_the_c_abi():
+    """40 000 exact duplicates of the query's best document overflow the candidate buffer of that query (capacity
+    4*32*c): the matrix-core pass refuses it, and the repair launches of the SAME library call answer it on the exact row
+    kernels — the raw ABI call (search_device: no host look at the result) returns what the one-query search returns."""
     from dewi import _engine as eng
     import torch
     n, dim, k = 100_000, 256, 10
@@ -87,11 +88,13 @@ def test_mfma_overflow_falls_back_to_exact_path():
     Q[5] = raw[7]                                     # query 5 hits the duplicated document
     q_dev = torch.from_numpy(Q).cuda()
     ids_raw, sc_raw = cb.search_device(q_dev, k, 0.0, 0.0)
+    assert cb.refused_by_last_call().tolist() == [j == 5 for j in range(32)]      # the pass really refused it (and only it)
     ids_raw, sc_raw = ids_raw.cpu().numpy(), sc_raw.cpu().numpy()
-    assert (ids_raw[5] == -1).all() and (np.delete(ids_raw, 5, axis=0) >= 0).all()
-    assert cb.unanswered(ids_raw).tolist() == [5]
-    assert cb.repair_unanswered(q_dev, ids_raw, sc_raw, k, 0.0, 0.0) == 1      # what callers of search_device do
-    ids, sc = cb.search(Q, k, 0.0, 0.0)               # blocking API repairs it by itself
+    assert ids_raw.min() >= 0 and not np.isnan(sc_raw).any()
+    one_ids, one_sc = cb.search_device(q_dev[5:6].contiguous(), k, 0.0, 0.0)      # one query: row kernels
+    assert not cb.refused_by_last_call().any()
+    assert np.array_equal(ids_raw[5], one_ids.cpu().numpy()[0]) and np.array_equal(sc_raw[5], one_sc.cpu().numpy()[0])
+    ids, sc = cb.search(Q, k, 0.0, 0.0)               # the blocking API is the same call
     assert np.array_equal(ids, ids_raw) and np.array_equal(sc, sc_raw)
     assert ids[5].tolist() == [7] + list(range(50_000, 50_009))      # ties: lower rows first
     assert np.allclose(sc[5], 1.0, atol=1e-2)
@@ -122,7 +125,8 @@ def test_pipelined_batches_in_both_spaces(space):
 def test_pipelined_batches_take_the_matrix_core_paths_and_equal_the_one_call_search(bf16, b):
     """dewi_knn_scan + dewi_knn_finish (two streams, rotating workspaces) choose the same path as the one-call
     search for a query batch — 256-query kernel, depth-split pass over a bf16 / an fp32 corpus — so the answers are
-    bit-equal; a refused query of a pipelined batch is answered again by ``drain``; shard records keep the marker."""
+    bit-equal; a refused query of a pipelined batch is repaired inside ``dewi_knn_finish`` (final results and shard
+    records alike: no marker leaves the library)."""
     from dewi import _engine as eng
     import torch
     n, dim, k = 100_000, 256, 10
@@ -135,9 +139,10 @@ def test_pipelined_batches_take_the_matrix_core_paths_and_equal_the_one_call_sea
     Q = orc.synth_queries(3 * b, dim, seed=4).reshape(3, b, dim)
     Q[1, 5] = raw[7]                                  # batch 1, query 5 overflows its survivor segments
     q_dev = torch.from_numpy(Q).cuda()
-    want = [c.search(Q[i], k, 0.3, 0.1) for i in range(3)]          # blocking API: repaired
+    want = [c.search(Q[i], k, 0.3, 0.1) for i in range(3)]
     raw_ids, _ = c.search_device(q_dev[1], k, 0.3, 0.1)
-    assert (raw_ids[5] == -1).all().item()                          # the one-call search refuses it too
+    assert c.refused_by_last_call().tolist() == [j == 5 for j in range(b)]     # the pass refuses it, the call answers it
+    assert np.array_equal(raw_ids.cpu().numpy(), want[1][0])
     pipe = eng.PipelinedSearcher(c, k, 0.3, 0.1, n_queries=b, depth=3, scan_streams=2)
     ids = torch.empty((3, b, k), dtype=torch.int64, device="cuda")
     sc = torch.empty((3, b, k), dtype=torch.float32, device="cuda")
@@ -152,4 +157,5 @@ def test_pipelined_batches_take_the_matrix_core_paths_and_equal_the_one_call_sea
     pipe2.submit(q_dev[1], out_records=recs)
     pipe2.drain()
     assert torch.equal(recs, c.candidates_device(q_dev[1], 2 * k))
-    assert (recs[5, :, 3] == -2).all().item()
+    assert (recs[:, :, 3] >= 0).all().item()                        # no refusal marker: query 5's records are real
+    assert torch.equal(recs[5], c.candidates_device(q_dev[1, 5:6].contiguous(), 2 * k)[0])   # == the row kernels' records

@@ -7,7 +7,7 @@ and fp32 accumulation; the three dropped cross terms are below 2^-23 of |q_i e_i
 fp32 rounding (dim 1536 keeps v_mfma_f32_32x32x2_f32 on the fp32 values).  So the oracle comparison is
 the plain fp32 one (tests/parity.py: ids exactly wherever the f64 decision gaps exceed 5e-7, scores to
 1e-5), and ``test_mfma_f32_heavy_tailed_components`` bounds the score error itself on vectors whose
-components span six orders of magnitude.  ``search_device`` is called, so a refused query (-1) would be
+components span six orders of magnitude.  ``search_device`` is called, so an unanswered query (-1) would be
 seen, not repaired.
 """
 import numpy as np
@@ -104,9 +104,9 @@ def test_mfma_f32_a_batch_of_four_stays_on_the_scan_kernels_and_agrees():
     check_batch(E, Q, dewi32, ent32, 10, 0.3, 0.0, "cosine", ids12, sc12, exact_gaps=False)
 
 
-def test_mfma_f32_overflow_falls_back_to_exact_path():
-    """40 000 exact duplicates of a query's best document overflow that query's survivor segments; the marker
-    (-1) makes the blocking search re-run it on the exact kernels."""
+def test_mfma_f32_overflow_is_repaired_behind_the_c_abi():
+    """40 000 exact duplicates of a query's best document overflow that query's survivor segments: the depth-split pass
+    refuses it and the repair launches of the same call answer it on the fp32 row kernels (raw ABI call, no host repair)."""
     from dewi import _engine as eng
     import torch
     n, dim, k = 100_000, 256, 10
@@ -116,12 +116,15 @@ def test_mfma_f32_overflow_falls_back_to_exact_path():
     c = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"])
     Q = orc.synth_queries(16, dim, seed=4)
     Q[5] = raw[7]
-    ids_raw, _ = c.search_device(torch.from_numpy(Q).cuda(), k, 0.0, 0.0)
-    ids_raw = ids_raw.cpu().numpy()
-    assert (ids_raw[5] == -1).all() and (np.delete(ids_raw, 5, axis=0) >= 0).all()
-    ids, sc = c.search(Q, k, 0.0, 0.0)
-    assert ids[5].tolist() == [7] + list(range(50_000, 50_009))
-    assert np.allclose(sc[5], 1.0, atol=1e-5)
+    q_dev = torch.from_numpy(Q).cuda()
+    ids_raw, sc_raw = c.search_device(q_dev, k, 0.0, 0.0)
+    assert c.refused_by_last_call().tolist() == [j == 5 for j in range(16)]
+    ids_raw, sc_raw = ids_raw.cpu().numpy(), sc_raw.cpu().numpy()
+    assert ids_raw.min() >= 0
+    one_ids, one_sc = c.search_device(q_dev[5:6].contiguous(), k, 0.0, 0.0)
+    assert np.array_equal(ids_raw[5], one_ids.cpu().numpy()[0]) and np.array_equal(sc_raw[5], one_sc.cpu().numpy()[0])
+    assert ids_raw[5].tolist() == [7] + list(range(50_000, 50_009))
+    assert np.allclose(sc_raw[5], 1.0, atol=1e-5)
 
 
 @pytest.mark.parametrize("space", ["cosine", "l2"])

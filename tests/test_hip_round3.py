@@ -158,10 +158,11 @@ def test_l2_exact_refine_equals_the_one_query_search(dim, k, b, qscale):
     cc = 2 * k
     recs = c.candidates_device(qd, cc)
     m_ids, m_sc = (t.cpu().numpy() for t in eng.merge_rerank_device(recs.unsqueeze(0), cc, k, 0.3, 0.1))
-    answered = m_ids[:, 0] >= 0          # (at qscale 20 the error band holds more candidates than the sort: such a query is
-    assert np.all(m_ids[~answered] == -1)   # REFUSED — records id -2, merge id -1 — and `search` re-ran it on the row kernels)
-    assert np.array_equal(m_ids[answered], ids[answered]) and np.array_equal(m_sc[answered], sc[answered])
-    assert answered.all() or qscale > 1.0
+    # (at qscale 20 the error band holds more candidates than the sort: the pass refuses such a query and the repair inside
+    # dewi_knn_candidates writes its records from the row kernels — nothing is marked, the merge answers every query)
+    assert not c.refused_by_last_call().any() or qscale > 1.0
+    assert m_ids.min() >= 0
+    assert np.array_equal(m_ids, ids) and np.array_equal(m_sc, sc)
 
 
 @pytest.mark.parametrize("bf16", [False, True])
@@ -308,9 +309,9 @@ def test_redundancy_top1_at_full_size():
         assert abs(float(sims.max()) - float(r[i])) < 2e-3, i
 
 
-def test_drain_repairs_a_refused_query_with_the_shards_id_offset():
-    """PipelinedSearcher.drain answers a query the matrix-core pass refused again on the exact kernels: the repaired
-    row must carry the shard's id offset like the rows dewi_knn_finish wrote."""
+def test_finish_repairs_a_refused_query_with_the_shards_id_offset():
+    """dewi_knn_finish answers a query the matrix-core pass refused on the exact kernels itself (ABI 5): the repaired row
+    carries the shard's id offset like every other row it writes — nothing is left for ``drain`` to do."""
     import torch
     eng = _engine()
     n, dim, k, b, off = 100_000, 256, 10, 40, 5_000_000
@@ -320,16 +321,17 @@ def test_drain_repairs_a_refused_query_with_the_shards_id_offset():
     c = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"], id_offset=off).to_bf16()
     Q = orc.synth_queries(b, dim, seed=4)
     Q[5] = raw[7]                                                 # overflows its survivor segments
-    want_ids, want_sc = c.search(Q, k, 0.3, 0.1)                  # blocking API: repaired, global ids
+    want_ids, want_sc = c.search(Q, k, 0.3, 0.1)                  # global ids
     assert want_ids.min() >= off
+    assert c.refused_by_last_call().tolist() == [j == 5 for j in range(b)]
     q_dev = torch.from_numpy(Q).cuda()
-    raw_ids, _ = c.search_device(q_dev, k, 0.3, 0.1)
-    assert (raw_ids[5] == -1).all().item()
+    one_ids, one_sc = c.search(Q[5], k, 0.3, 0.1)
+    assert np.array_equal(want_ids[5], one_ids[0]) and np.array_equal(want_sc[5], one_sc[0])
     pipe = eng.PipelinedSearcher(c, k, 0.3, 0.1, n_queries=b)
     ids = torch.empty((b, k), dtype=torch.int64, device="cuda")
     sc = torch.empty((b, k), dtype=torch.float32, device="cuda")
     pipe.submit(q_dev, ids, sc)
-    pipe.drain()
+    pipe.finish_stream.synchronize()                              # no drain-side repair exists any more
     assert np.array_equal(ids.cpu().numpy(), want_ids) and np.array_equal(sc.cpu().numpy(), want_sc)
 
 
@@ -516,11 +518,13 @@ def test_one_query_through_the_bf16_shadow_equals_the_fp32_row_scan(dim, n, k):
     assert int(d_ids[0, 0]) == 4242 or k > 1                          # eta = 0.3: the copy leads unless DEWI outweighs it
     two = eng.DeviceCorpus(plain.emb, plain.dewi32, plain.ent32, "cosine").enable_bf16_shadow()
     assert two.shadow_min_batch == 2
-    # the one-query call really reads the shadow: with the shadow zeroed every row ties at 0, the survivors overflow and the
-    # raw call comes back refused — while the corpus without the switch (and the repair inside search()) never looks at it
+    # the one-query call really reads the shadow: with the shadow zeroed every row ties at 0, the survivors overflow, the
+    # pass refuses the query — and the repair launches of the same call answer it from the fp32 rows (ABI 5) — while the
+    # corpus without the switch never looks at the shadow
     c.shadow.zero_()
-    z_ids, _ = c.search_device(qd[5:6].contiguous(), k, 0.3, 0.1)
-    assert int(z_ids[0, 0]) == -1
+    z_ids, z_sc = c.search_device(qd[5:6].contiguous(), k, 0.3, 0.1)
+    assert c.refused_by_last_call().tolist() == [True]
+    assert torch.equal(z_ids, p_ids) and torch.equal(z_sc, p_sc)
     two.shadow.zero_()
     t_ids, t_sc = two.search_device(qd[5:6].contiguous(), k, 0.3, 0.1)
     assert torch.equal(t_ids, p_ids) and torch.equal(t_sc, p_sc)
@@ -579,8 +583,8 @@ def test_exact_index_with_batch_shadow_answers_as_the_plain_index():
 
 def test_one_query_through_the_shadow_is_repaired_when_the_pass_refuses_it():
     """A corpus with 20 000 copies of one row: the pre-selection's survivors of a query that points at them overflow the
-    segment, the pass refuses the query (id -1), and search() answers it on the plain fp32 scan — the same answer as
-    the unshadowed corpus gives."""
+    segment, the pass refuses the query, and the repair launches behind it (same library call, same stream) answer it on
+    the plain fp32 scan — the raw ABI call returns the same answer as the unshadowed corpus gives."""
     import torch
     eng = _engine()
     n, dim, k = 90_000, 256, 10
@@ -590,12 +594,12 @@ def test_one_query_through_the_shadow_is_repaired_when_the_pass_refuses_it():
     plain = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"])
     c = eng.DeviceCorpus(plain.emb, plain.dewi32, plain.ent32, "cosine").enable_bf16_shadow(single_query=True)
     q = raw[5] * 2.0
-    raw_ids, _ = c.search_device(torch.from_numpy(q[None]).cuda(), k, 0.3, 0.1)
-    ids, sc = c.search(q, k, 0.3, 0.1)
+    raw_ids, raw_sc = c.search_device(torch.from_numpy(q[None]).cuda(), k, 0.3, 0.1)
+    assert c.refused_by_last_call().tolist() == [True]            # 20 000 rows inside the error band: refused, then repaired
     i1, s1 = plain.search(q, k, 0.3, 0.1)
+    assert np.array_equal(raw_ids.cpu().numpy(), i1) and np.array_equal(raw_sc.cpu().numpy(), s1)
+    ids, sc = c.search(q, k, 0.3, 0.1)
     assert ids.min() >= 0 and np.array_equal(ids, i1) and np.array_equal(sc, s1)
-    # (whether the raw call was refused depends on the segment capacity; either way the blocking answer is the exact one)
-    assert int(raw_ids[0, 0]) == -1 or np.array_equal(raw_ids.cpu().numpy(), i1)
 
 
 def test_bf16_shadow_refuses_rows_that_are_not_normalised():
@@ -609,11 +613,15 @@ def test_bf16_shadow_refuses_rows_that_are_not_normalised():
         eng.DeviceCorpus(emb, z, z, "l2").enable_bf16_shadow()
 
 
-def test_refine_routes_when_the_survivors_do_not_fit_the_staging():
+@pytest.mark.parametrize("switch", [{"DEWI_STAGE_KEYS": "512"}, {"DEWI_SELECT_THREADS": "256"}],
+                         ids=["staging-512-keys", "more-segments-than-threads"])
+def test_refine_routes_when_the_survivors_do_not_fit_the_staging(switch):
     """The exact-refine select stages a query's survivors in LDS; when there are more than it holds it takes the same
     steps over the segments in global memory instead of refusing.  A child process with the staging shrunk to 512 keys
     (DEWI_STAGE_KEYS, a test switch) runs the bf16-shadow batch and the l2 batch that way: both must still equal the
-    one-query searches bit for bit."""
+    one-query searches bit for bit.  Second switch (DEWI_SELECT_THREADS=256): the 256-query pass's 1024 segments then
+    outnumber the select's threads — that route must refine too (it used to sort the approximate keys as they stood:
+    round 3's advice), never return bf16 scores as the exact answer."""
     import os
     import subprocess
     import sys
@@ -640,5 +648,5 @@ for j in range(b):
 print('OK')
 """ % (repo / "dewi-design-for-an-entropy-weighted-index-for-text-image-corpora_amd", repo / "oracle")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, DEWI_STAGE_KEYS="512"))
+                       env=dict(os.environ, **switch))
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stderr[-3000:]

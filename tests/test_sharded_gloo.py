@@ -211,9 +211,9 @@ def _gpu_worker_bf16(rank, world, port, duplicates, ret):
         local = build_local_shard(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"], rank, world).to_bf16()
         s = ShardedSearcher(local, local.n_rows)
         out = {"final": s.search(Q, _BF16["k"], 0.3, 0.2)}
-        if duplicates:   # the raw records of the overflowed query carry the marker on the shard that overflowed
+        if duplicates:   # the shard whose pass refused the overflowed query repairs it inside dewi_knn_candidates (ABI 5)
             recs = local.candidates_device(local.stage_queries(Q), s.n_candidates(_BF16["k"])).cpu().numpy()
-            out["marker"] = (int(recs[5, 0, 3]), int(recs[4, 0, 3]))
+            out["marker"] = (int(recs[5, 0, 3]), int(recs[4, 0, 3]), bool(local.refused_by_last_call()[5]))
         ret[rank] = out
     finally:
         dist.destroy_process_group()
@@ -233,8 +233,9 @@ def test_two_bf16_shards_batched_path_equal_single_device(duplicates):
         assert np.array_equal(ret[r]["final"][0], ids), r
         assert np.array_equal(ret[r]["final"][1], sc), r
     if duplicates:
-        assert ret[1]["marker"][0] == -2 and ret[1]["marker"][1] >= 0     # shard 1 overflowed on query 5 only
-        assert ret[0]["marker"][0] >= 0                                   # shard 0 answered it
+        assert ret[1]["marker"][2] and not ret[0]["marker"][2]            # shard 1's pass refused query 5, shard 0's did not
+        assert ret[1]["marker"][0] >= 0 and ret[1]["marker"][1] >= 0      # ... and its records are real all the same
+        assert ret[0]["marker"][0] >= 0
         assert ids[5, 0] == 7 or ids[5, 0] >= 100_000                    # the duplicated document wins
 
 
