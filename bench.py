@@ -442,7 +442,8 @@ def run_c2(args, torch, dist, eng, nat, rank, world, device):
     # --batch >= 5 over the fp32 corpus: the depth-split matrix-core pass is the dominant kernel (one per 32 queries);
     # --batch > 32: the 256-query pass over the bf16 shadow (one per 256 queries)
     # --batch 1 --shadow 1 (cut of at most 32 rows): the bf16 ROW kernel over the shadow
-    kernel = ("scan_rows_f32" if (B < 5 and not shadowed) else f"mfma_scan_f32<false,{args.dim // 256},false,false>" if not shadowed
+    # (the library names the row kernel of this width itself: the tuned dim = 256 U kernels, the any-width ones, the generic)
+    kernel = (corpus.scan_kernel_name(B, k) if (B < 5 and not shadowed) else f"mfma_scan_f32<false,{args.dim // 256},false,false>" if not shadowed
               else f"mfma_scan_bf16_s16<{args.dim // 16},false>" if B > 32
               else f"scan_rows_bf16<{args.dim // 256},1,0,1,true>" if (B == 1 and c <= 32 and args.dim <= 1024)   # (no bf16 row kernel at 1536)
               else f"mfma_scan_f32<true,{args.dim // 256},false,false>")

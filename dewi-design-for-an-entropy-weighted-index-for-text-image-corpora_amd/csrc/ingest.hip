@@ -21,20 +21,21 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
   for (int64_t row = gwave; row < n_rows; row += n_waves) {
     const float* s = src + row * dim;
     float* d = dst + row * dim;
-    float ss = 0.f;
+    // ||row|| as the query kernels compute ||q|| (common.hpp wave_query_norm): squares and their sum in float64, ONE rounding
+    // to fp32 after the square root — within half an ulp of the true norm, where the reference's np.linalg.norm
+    // (backends.py:399-401: an fp32 BLAS dot product in an unspecified order) is within ~1.5; the stored rows then agree with
+    // the reference's to 1 ulp on the golden inputs (2 ulp bound; tests/test_hip_index_api.py compares the saved matrices)
+    double ss = 0.0;
     if constexpr (VEC == 4) {
       const f32x4* sv = reinterpret_cast<const f32x4*>(s);
       for (int u = lane; u < dim / 4; u += kWave) {
         const f32x4 v = sv[u];
-        ss = __builtin_fmaf(v.x, v.x, ss);
-        ss = __builtin_fmaf(v.y, v.y, ss);
-        ss = __builtin_fmaf(v.z, v.z, ss);
-        ss = __builtin_fmaf(v.w, v.w, ss);
+        ss += square_f64(v.x) + square_f64(v.y) + square_f64(v.z) + square_f64(v.w);
       }
     } else {
-      for (int j = lane; j < dim; j += kWave) ss = __builtin_fmaf(s[j], s[j], ss);
+      for (int j = lane; j < dim; j += kWave) ss += square_f64(s[j]);
     }
-    const float norm = __fsqrt_rn(wave_sum_f32(ss));
+    const float norm = wave_query_norm(ss);
     // no zero-norm guard, like the reference: 0/0 -> NaN
     if constexpr (VEC == 4) {
       const f32x4* sv = reinterpret_cast<const f32x4*>(s);

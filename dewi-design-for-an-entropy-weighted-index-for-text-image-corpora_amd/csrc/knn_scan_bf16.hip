@@ -189,11 +189,10 @@ __global__ __launch_bounds__(kScanThreads) void scan_rows_bf16_flagged(const uin
                                                                        uint64_t* __restrict__ keys, int64_t keys_per_query,
                                                                        const uint32_t* __restrict__ flags, int n_queries) {
   __shared__ MergeShared merge_buf;
-  for (int q = 0; q < n_queries; ++q) {
-    if (flags[q] == 0u) continue;   // wave-uniform
+  for_each_flagged(flags, n_queries, [&](int q) {
     scan_rows_bf16_body<H, 1, SPACE, S, true>(E, n_rows, Q + static_cast<int64_t>(q) * (256 * H), n_candidates,
                                               keys + static_cast<int64_t>(q) * keys_per_query, keys_per_query, merge_buf);
-  }
+  });
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -227,11 +227,10 @@ __global__ __launch_bounds__(kScanThreads) void scan_rows_any_flagged(const u32x
                                                                       const uint32_t* __restrict__ flags, int n_queries) {
   __shared__ MergeShared merge_buf;
   const int dim = units * (ELEM ? 8 : 4);
-  for (int q = 0; q < n_queries; ++q) {
-    if (flags[q] == 0u) continue;   // wave-uniform
+  for_each_flagged(flags, n_queries, [&](int q) {
     scan_rows_any_body<ELEM, U, R, 1, SPACE, S>(E, n_rows, units, Q + static_cast<int64_t>(q) * dim, n_candidates,
                                                 keys + static_cast<int64_t>(q) * keys_per_query, keys_per_query, merge_buf);
-  }
+  });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -352,11 +351,10 @@ __global__ __launch_bounds__(kScanThreads) void scan_short_rows_any_flagged(cons
                                                                             const uint32_t* __restrict__ flags, int n_queries) {
   __shared__ MergeShared merge_buf;
   const int dim = units * (ELEM ? 8 : 4);
-  for (int q = 0; q < n_queries; ++q) {
-    if (flags[q] == 0u) continue;   // wave-uniform
+  for_each_flagged(flags, n_queries, [&](int q) {
     scan_short_rows_any_body<ELEM, R, 1, SPACE, S>(E, n_rows, units, log2p, Q + static_cast<int64_t>(q) * dim, n_candidates,
                                                    keys + static_cast<int64_t>(q) * keys_per_query, keys_per_query, merge_buf);
-  }
+  });
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -171,4 +171,21 @@ __device__ __forceinline__ void block_merge_store(const WaveList<1>& lst, MergeS
   }
 }
 
+// Repair launches: call f(q) for every query whose flag is set.  One vector load + one ballot per 64 queries (a loop of
+// scalar loads, one per query, cost a 256-query batch ~25 us of latency in every workgroup even with nothing to repair).
+template <class F>
+__device__ __forceinline__ void for_each_flagged(const uint32_t* __restrict__ flags, int n_queries, F f) {
+  const int lane = lane_id();
+  for (int base = 0; base < n_queries; base += kWave) {
+    const int q = base + lane;
+    const uint32_t v = q < n_queries ? flags[q] : 0u;
+    unsigned long long m = __ballot(v != 0u);
+    while (m != 0ull) {   // wave-uniform
+      const int j = __ffsll(m) - 1;
+      m &= m - 1ull;
+      f(base + j);
+    }
+  }
+}
+
 }  // namespace dewi

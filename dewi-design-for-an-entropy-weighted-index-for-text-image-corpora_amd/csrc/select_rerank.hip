@@ -1064,6 +1064,9 @@ hipError_t launch_select_rerank(const uint64_t* d_keys, int64_t keys_per_query, 
   } else if (keys_per_query <= 4096 && n_candidates <= 128 && refine.E == nullptr) {
     threads = 256;   // (refine mode re-scores its candidates one wave each: sixteen waves)
   }
+  // the repair's select returns at once for every query but the refused ones (rare): launch it small — 4 waves per query
+  // instead of 16 cost the usual batch less to dispatch, and a refused query's select is not where its time goes
+  if (flags.mode == 2) threads = 256;
   // DEWI_SELECT_THREADS (tests only, 256 .. 1024): fewer threads than survivor segments puts a matrix-core batch on the
   // kernel's more-segments-than-threads route
   static const int threads_override = [] { const char* e = getenv("DEWI_SELECT_THREADS"); return e ? atoi(e) : 0; }();

@@ -391,7 +391,9 @@ class PipelinedSearcher:
         self.finish_stream.synchronize()
 
 
-_merge_ws: Dict[object, "torch.Tensor"] = {}      # per device: scratch of the large merge (stream-ordered reuse)
+# scratch of the large merge, one buffer per (device, stream): reuse is ordered by the stream it is used on, so two streams
+# (the current stream beside a PipelinedSearcher / sharded finish stream) or two threads never share one
+_merge_ws: Dict[object, "torch.Tensor"] = {}
 
 
 def merge_rerank_device(lists, n_candidates: int, k: int, eta: float, entropy_pref: float, out_ids=None,
@@ -408,9 +410,14 @@ def merge_rerank_device(lists, n_candidates: int, k: int, eta: float, entropy_pr
     need = int(lib.dewi_merge_workspace_bytes(n_lists, b, list_len, int(n_candidates)))
     ws = None
     if need:
-        ws = _merge_ws.get(lists.device)
+        key = (lists.device, int(torch.cuda.current_stream(lists.device).cuda_stream))
+        ws = _merge_ws.get(key)
         if ws is None or ws.numel() < need:
-            ws = _merge_ws[lists.device] = torch.empty(need, dtype=torch.uint8, device=lists.device)
+            if len(_merge_ws) > 16:
+                _merge_ws.clear()
+            # (a buffer that is outgrown is only dropped here: the caching allocator keeps its memory stream-ordered, so a
+            # merge still running on this stream finishes on it before anything else of this stream can take the block)
+            ws = _merge_ws[key] = torch.empty(need, dtype=torch.uint8, device=lists.device)
     rc = lib.dewi_merge_rerank(nat.ptr(lists), n_lists, b, list_len, int(n_candidates), int(k), float(eta),
                                float(entropy_pref), nat.ptr(out_ids), nat.ptr(out_scores),
                                nat.ptr(ws) if ws is not None else None, need, nat.stream_ptr())

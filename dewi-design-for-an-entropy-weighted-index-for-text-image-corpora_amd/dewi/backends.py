@@ -288,7 +288,8 @@ class ExactIndex(BaseIndex):
             if covered == n:
                 c64 = {}
                 for name in fields:
-                    parts = [(cols[name].to(device=dev, dtype=torch.float64) if name in cols
+                    # (a block may mix CUDA and host columns: PayloadStore keeps host ones as ndarrays — as_tensor takes both)
+                    parts = [(torch.as_tensor(cols[name]).to(device=dev, dtype=torch.float64) if name in cols
                               else torch.zeros(r1 - r0, dtype=torch.float64, device=dev)) for r0, r1, cols, _ in blocks]
                     c64[name] = (parts[0] if len(parts) == 1 else torch.cat(parts)).contiguous()
             else:

@@ -4,6 +4,8 @@ assertions, plus persistence interchange with directories the reference itself s
 import json
 
 import numpy as np
+
+import dewi_oracle as orc
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -180,6 +182,74 @@ def test_loads_directories_saved_by_the_reference(golden_dir):
     got = di.search(q, k=3)
     assert [r[0] for r in got] == [r[0] for r in exp["dewi_k3_defaults"]]
     assert np.allclose([r[1] for r in got], [r[1] for r in exp["dewi_k3_defaults"]], atol=1e-6)
+
+
+def _g5_inputs():
+    """The seeded inputs oracle/gen_golden.py g5() fed the reference (ids, raw rows, payloads, metadata)."""
+    from dewi.types import Payload
+    dim = 8
+    cols = orc.synth_payload_columns(6, seed=21)
+    keys = ("dewi", "ht_mean", "ht_q90", "hi_mean", "hi_q90", "I_hat", "redundancy", "noise")
+    rows = [np.random.RandomState(42 + i).randn(dim).astype(np.float32) for i in range(6)]
+    pays = [Payload(**{k: float(cols[k][i]) for k in keys}) for i in range(6)]
+    metas = [{"source": f"file{i}.txt"} if i % 2 == 0 else None for i in range(6)]
+    return dim, [f"id-{i}" for i in range(6)], rows, pays, metas
+
+
+def _assert_same_saved_index(mine, ref):
+    """metadata.json equal as JSON incl. key order, payloads.jsonl line for line, embeddings.npy same dtype / shape /
+    C order and at most 2 ulp per element: the reference divides by ``np.linalg.norm`` — an fp32 BLAS dot product, up to
+    ~1.5 ulp off the true norm in an order NumPy does not specify — where the device divides by the float64-summed norm
+    rounded once (<= 0.5 ulp); each quotient adds its own half ulp.  (Measured on these 48 values: 39 equal, 8 one ulp,
+    1 two ulp.)"""
+    a, b = json.loads((mine / "metadata.json").read_text()), json.loads((ref / "metadata.json").read_text())
+    assert a == b and list(a) == list(b), (a, b)
+    assert (mine / "payloads.jsonl").read_text().splitlines() == (ref / "payloads.jsonl").read_text().splitlines()
+    ea, eb = np.load(mine / "embeddings.npy", allow_pickle=False), np.load(ref / "embeddings.npy", allow_pickle=False)
+    assert ea.dtype == eb.dtype == np.float32 and ea.shape == eb.shape and ea.flags["C_CONTIGUOUS"] and not np.isfortran(ea)
+    ulp = np.spacing(np.abs(eb).astype(np.float32))
+    assert np.all(np.abs(ea - eb) <= 2 * ulp), float(np.max(np.abs(ea - eb) / ulp))
+    assert sorted(p.name for p in mine.iterdir()) == sorted(p.name for p in ref.iterdir())
+
+
+@pytest.mark.parametrize("bulk", [False, True], ids=["add", "add_batch"])
+def test_saves_what_the_reference_saves(golden_dir, tmp_path, bulk):
+    """G5, write side (reference backends.py:483-513, index.py:121-146): the same seeded inputs ingested here (one-row
+    ``add`` as the reference's generator did, or the bulk path), built on the GPU and saved, against the directories the
+    reference itself wrote — file names, JSON keys and their order, payload lines, the embedding matrix."""
+    from dewi.index import DewiIndex, ExactIndex
+    dim, ids, rows, pays, metas = _g5_inputs()
+    ex = ExactIndex(dim=dim, space="cosine")
+    di = DewiIndex(dim=dim, backend="auto", use_ann=False, rerank_eta=0.4, entropy_pref=0.1)
+    if bulk:
+        ex.add_batch(ids, np.stack(rows), pays)
+        di.add_batch(ids[:3], np.stack(rows[:3]), pays[:3])          # bulk blocks and single rows mixed
+        for i in range(3, 6):
+            di.add(ids[i], rows[i], pays[i], meta=metas[i])
+        di._meta.update({ids[i]: metas[i] for i in range(3) if metas[i] is not None})   # (add_batch takes no metadata)
+        di._meta = {k: di._meta[k] for k in sorted(di._meta)}
+    else:
+        for i in range(6):
+            ex.add(ids[i], rows[i], pays[i])
+            di.add(ids[i], rows[i], pays[i], meta=metas[i])
+    ex.build()
+    di.build()
+    ex.save(tmp_path / "ex")
+    di.save(tmp_path / "di")
+    _assert_same_saved_index(tmp_path / "ex", golden_dir / "g5_exact_index")
+    ref = golden_dir / "g5_dewi_index"
+    mine = tmp_path / "di"
+    for name in ("config.json", "meta.json"):
+        a, b = json.loads((mine / name).read_text()), json.loads((ref / name).read_text())
+        assert a == b and list(a) == list(b), (name, a, b)
+    assert sorted(p.name for p in mine.iterdir()) == sorted(p.name for p in ref.iterdir())
+    _assert_same_saved_index(mine / "ann_index", ref / "ann_index")
+    # and the reference's own answers on its saved index come back from ours
+    exp = json.loads((golden_dir / "g5_expected.json").read_text())
+    q = np.array(exp["query"], np.float32)
+    got = ExactIndex.load(tmp_path / "ex").search(q, k=3, eta=0.5)
+    assert [r[0] for r in got] == [r[0] for r in exp["exact_k3_eta0.5"]]
+    assert np.allclose([r[1] for r in got], [r[1] for r in exp["exact_k3_eta0.5"]], atol=1e-6)
 
 
 def test_batch_api_equals_single_queries():

@@ -18,9 +18,11 @@ from parity import check_batch, device_prepared_queries
 
 pytestmark = pytest.mark.gpu
 
-# space="l2" on the matrix cores is opt-in (dewi_tuning_set batched_mfma = 2: its score 2<e,q> - ||e||^2 - ||q||^2 has an
-# absolute error of ~ulp(||e||^2 + ||q||^2); by default l2 batches take the exact row kernels, tests/test_hip_round3.py).
-# This module tests the matrix-core passes themselves, in both spaces: every test runs opted in.
+# The UNREFINED form of space="l2" on the matrix cores is an opt-in (dewi_tuning_set batched_mfma = 2: its score
+# 2<e,q> - ||e||^2 - ||q||^2 has an absolute error of ~ulp(||e||^2 + ||q||^2)).  By default l2 batches over an fp32 corpus
+# take the pass in exact-refine mode (bit-equal to the one-query search; tests/test_hip_round3.py checks that mode against
+# the oracle and against the one-query search) and l2 batches over a bf16 corpus the exact row kernels.
+# This module tests the matrix-core passes themselves, unrefined, in both spaces: every test runs opted in.
 MFMA_ON = 2
 
 

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import dewi_oracle as orc
-from parity import compare_query
+from parity import check_batch, compare_query
 
 pytestmark = pytest.mark.gpu
 
@@ -163,6 +163,27 @@ def test_l2_exact_refine_equals_the_one_query_search(dim, k, b, qscale):
     assert not c.refused_by_last_call().any() or qscale > 1.0
     assert m_ids.min() >= 0
     assert np.array_equal(m_ids, ids) and np.array_equal(m_sc, sc)
+
+
+@pytest.mark.parametrize("dim,n,b,k", [(768, 70_001, 32, 10), (256, 131_073, 12, 10), (512, 80_000, 40, 50)])
+def test_default_l2_batches_over_fp32_vs_oracle(dim, n, b, k):
+    """The DEFAULT mode of space="l2" batches over an fp32 corpus (matrix-core pass + exact refinement; nothing opted in)
+    through the oracle harness at the floors the unrefined tests had before round 3 (80 % decisive at k <= 10, 25 % above):
+    rows and queries of very different lengths, as tests/test_hip_mfma_f32.py::test_mfma_l2_batched_vs_oracle."""
+    import torch
+    eng = _engine()
+    rng = np.random.default_rng(dim + b)
+    raw = orc.synth_corpus(n, dim, seed=dim + b) * rng.uniform(0.5, 2.0, size=(n, 1)).astype(np.float32)
+    Q = orc.synth_queries(b, dim, seed=b) * rng.uniform(0.5, 2.0, size=(b, 1)).astype(np.float32)
+    cols = orc.synth_payload_columns(n, seed=dim + b)
+    c = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"], space="l2")
+    assert c.scan_kernel_name(b, k).startswith("mfma_scan_f32")          # the default really is the matrix-core pass
+    dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    ids_d, sc_d = c.search_device(torch.from_numpy(Q).cuda(), k, 0.3, 0.1)
+    ids, sc = ids_d.cpu().numpy(), sc_d.cpu().numpy()
+    assert ids.min() >= 0 and not np.isnan(sc).any()
+    check_batch(raw, Q, dewi32, ent32, k, 0.3, 0.1, "l2", ids, sc, min_decisive_frac=0.8 if k <= 10 else 0.25,
+                exact_gaps=False)
 
 
 @pytest.mark.parametrize("bf16", [False, True])
@@ -380,6 +401,15 @@ def test_device_ingest_paths_equal_host_ingest(tmp_path):
         a.add_batch_columns(ids[1000:1800], raw[1000:1800], {f: cols[f][1000:1800] for f in fields})
         a.add_batch_columns(ids[1800:], torch.from_numpy(raw[1800:]).cuda(), dev_cols(1800, n))
         got = a.search_batch(Q, k, 0.3, 0.2)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), space
+        # (a') ONE block whose payload columns are mixed — some CUDA tensors, some host arrays (round 3's advice: the
+        # device-covered build used to call .to() on an ndarray)
+        m = ExactIndex(dim=d, space=space)
+        mixed = dev_cols(0, n)
+        mixed["hi_mean"] = cols["hi_mean"]                       # a host column among device ones
+        mixed["noise"] = cols["noise"]
+        m.add_batch_columns(ids, torch.from_numpy(raw).cuda(), mixed, copy=True)
+        got = m.search_batch(Q, k, 0.3, 0.2)
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), space
         # (b) rows appended to a built index (stored rows are not normalised twice)
         b = ExactIndex(dim=d, space=space)
