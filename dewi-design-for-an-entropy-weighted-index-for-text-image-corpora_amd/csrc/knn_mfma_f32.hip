@@ -105,6 +105,13 @@ constexpr int depth_lds_bytes() { return DepthGeo<BF16>::kRing * DepthGeo<BF16>:
 #ifndef DEWI_F32_SPLIT
 #define DEWI_F32_SPLIT 1
 #endif
+#ifndef DEWI_F32_PENDING2
+#define DEWI_F32_PENDING2 0   // 1 = two waiting places per accumulator register instead of one (a wave then flushes when a THIRD
+                              // survivor meets two waiting ones: fewer flushes).  Round 4, three interleaved rounds on one box
+                              // (scripts/probes/r04_f32_pending.sh, 1 M x 768, 32 queries): pass 0.4657-0.4667 ms with two places
+                              // against 0.4600-0.4606 with one — SLOWER by 6 us: the flush count is not what the pass waits for;
+                              // the select chains that keep two places cost more than the flushes they save.  Off.
+#endif
 #ifndef DEWI_F32_DEFER_FILTER
 #define DEWI_F32_DEFER_FILTER 1   // filter (and survivor stores) of a tile one chunk later, right behind a barrier
 #endif
@@ -343,6 +350,12 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
   constexpr uint32_t kNoDoc = 0xffffffffu;
   uint32_t pend_doc0 = kNoDoc, pend_doc1 = kNoDoc;
   float pend_s0 = 0.f, pend_s1 = 0.f;
+#if DEWI_F32_PENDING2
+  // a SECOND waiting place per accumulator register (round 4): the wave flushes when a THIRD survivor meets two waiting
+  // ones, which takes more than twice as many survivors as two meeting (birthday scaling: ~14 -> ~40 per wave)
+  uint32_t pend_doc0b = kNoDoc, pend_doc1b = kNoDoc;
+  float pend_s0b = 0.f, pend_s1b = 0.f;
+#endif
   auto flush_pending = [&]() {
     const uint32_t cap = static_cast<uint32_t>(out_stride);
     uint64_t* seg = out + (static_cast<int64_t>(blockIdx.x) * kF32Queries + r) * out_stride;
@@ -364,6 +377,18 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
       if (slot < cap && !DEWI_F32_ABLATE_STORES) seg[slot] = (static_cast<uint64_t>(pend_doc1) << 32) | __float_as_uint(pend_s1);
       pend_doc1 = kNoDoc;
     }
+#if DEWI_F32_PENDING2
+    if (pend_doc0b != kNoDoc) {
+      const uint32_t slot = take_slot();
+      if (slot < cap && !DEWI_F32_ABLATE_STORES) seg[slot] = (static_cast<uint64_t>(pend_doc0b) << 32) | __float_as_uint(pend_s0b);
+      pend_doc0b = kNoDoc;
+    }
+    if (pend_doc1b != kNoDoc) {
+      const uint32_t slot = take_slot();
+      if (slot < cap && !DEWI_F32_ABLATE_STORES) seg[slot] = (static_cast<uint64_t>(pend_doc1b) << 32) | __float_as_uint(pend_s1b);
+      pend_doc1b = kNoDoc;
+    }
+#endif
   };
   auto stage2_finish = [&](int64_t it) {             // fixed summation order 0..7 whichever wave sums; then the filter
     float s0 = 0.f, s1 = 0.f;
@@ -426,6 +451,24 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
       // sixty-four (a batch of 32 ran 40 us behind a batch of 8 on per-survivor stores; taking the LDS slots
       // alone cost nothing), and a wave collects ~14 survivors before two meet.
       const bool pass0 = !(s0 + m0 < thr_l), pass1 = !(s1 + m1 < thr_l);   // NaN passes (NumPy ranks NaN first)
+#if DEWI_F32_PENDING2
+      if (__builtin_amdgcn_ballot_w64((pass0 && pend_doc0 != kNoDoc && pend_doc0b != kNoDoc) ||
+                                      (pass1 && pend_doc1 != kNoDoc && pend_doc1b != kNoDoc)) != 0ull) flush_pending();
+      if (pass0) {
+        const bool first_free = pend_doc0 == kNoDoc;
+        pend_doc0b = first_free ? pend_doc0b : static_cast<uint32_t>(doc);
+        pend_s0b = first_free ? pend_s0b : s0;
+        pend_doc0 = first_free ? static_cast<uint32_t>(doc) : pend_doc0;
+        pend_s0 = first_free ? s0 : pend_s0;
+      }
+      if (pass1) {
+        const bool first_free = pend_doc1 == kNoDoc;
+        pend_doc1b = first_free ? pend_doc1b : static_cast<uint32_t>(doc + 1);
+        pend_s1b = first_free ? pend_s1b : s1;
+        pend_doc1 = first_free ? static_cast<uint32_t>(doc + 1) : pend_doc1;
+        pend_s1 = first_free ? s1 : pend_s1;
+      }
+#else
       if (__builtin_amdgcn_ballot_w64((pass0 && pend_doc0 != kNoDoc) || (pass1 && pend_doc1 != kNoDoc)) != 0ull) flush_pending();
       if (pass0) {
         pend_doc0 = static_cast<uint32_t>(doc);
@@ -435,6 +478,7 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
         pend_doc1 = static_cast<uint32_t>(doc + 1);
         pend_s1 = s1;
       }
+#endif
     }
   };
 
