@@ -173,7 +173,7 @@ int run_scan(const KnnLayout& L, const void* d_E, int elem_type, int64_t n_rows,
     // queries per corpus pass: 8 (fp32 row-per-wave kernel with one sorted list per workgroup), else 4, else 1
     static const bool nq8_enabled = [] { const char* e = getenv("DEWI_SCAN_NQ8"); return e == nullptr || atoi(e) != 0; }();
     const bool can8 = !elem_type && L.plan.fast && L.plan.slots == 1 && nq8_enabled;
-    const int nq = (can8 && n_queries - q >= 8) ? 8 : ((n_queries - q >= L.plan.nq_max) ? L.plan.nq_max : 1);
+    const int nq = (can8 && n_queries - q >= 8) ? 8 : ((L.plan.nq_max > 1 && n_queries - q >= L.plan.nq_max) ? L.plan.nq_max : 1);
     if (elem_type)
       e = dewi::launch_scan_bf16(L.plan, static_cast<const uint16_t*>(d_E), n_rows, dim, d_Q, L.plan.raw_queries ? nullptr : qn,
                                  q, nq, n_candidates, space, keys, stream);

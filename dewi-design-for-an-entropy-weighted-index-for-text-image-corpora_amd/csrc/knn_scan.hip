@@ -392,7 +392,7 @@ ScanPlan plan_scan(int64_t n_rows, int dim, int elem_bytes, int n_candidates, in
       p.units = n_units;
       for (int v : pads)
         if (v >= need) { p.u_pad = v; break; }
-      if (p.u_pad > 8) p.nq_max = 2;
+      p.nq_max = any_nq_max(elem_bytes, p.u_pad);
       // (sweeps: dewi_tuning_set rows_per_iter = 1, 2, 3 picks the level instead of the width)
       p.level = tuning.rows_per_iter > 0 ? (tuning.rows_per_iter - 1) % kAnyLevels : any_level(n_units);
       p.rows_per_iter = any_rows(p.u_pad, 1, p.level);

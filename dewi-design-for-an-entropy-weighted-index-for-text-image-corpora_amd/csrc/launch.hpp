@@ -65,7 +65,7 @@ struct ScanPlan {
   int u_pad;          // kScanAnyLong: units per lane the instantiated kernel holds (>= ceil(units / 64))
   int log2p;          // kScanAnyShort: log2 of the lanes that share a row
   int level;          // kScanAnyLong: which rows-in-flight choice of its units-per-lane count (scan_any.hpp any_level / any_rows)
-  int nq_max;         // most queries one corpus pass of the row kernel serves besides 1 (4; 2 for rows beyond 512 units)
+  int nq_max;         // most queries one corpus pass of the row kernel serves besides 1 (4; 2 or 1 for wide rows: scan_any.hpp any_nq_max)
   bool raw_queries;   // the kernel normalises the raw queries itself (everything but kScanGeneric)
   int64_t keys_per_query;  // number of uint64 keys the scan emits per query
   bool nontemporal;

@@ -5,8 +5,8 @@
 // columns too long for this one).  That path streams every column six times through fifteen launches
 // (7 x 1M: 74-99 us, launch-gap bound).  Here a phase is ONE kernel:
 //
-//   1. every workgroup of a column derives the same BRACKET [lo, hi] of keys from a strided sample of
-//      4096 values: the sample's ranks m/2 -/+ 208 (6.5 sigma of a sample median's rank), widened to
+//   1. every workgroup of a column derives the same BRACKET [lo, hi] of keys from a sample of 4096 values
+//      (256 runs of 16 consecutive values: 256 cache lines): the sample's ranks m/2 -/+ 208 (6.5 sigma of a sample median's rank), widened to
 //      22-bit key prefixes (LDS histogram passes) — a guess, verified below, never trusted;
 //   2. ONE pass over the column: count the keys below lo, equal to lo, equal to hi, the NaNs, and
 //      COLLECT the keys strictly inside the bracket (~10 % of the column) into 16 BUCKETS by the top
@@ -323,14 +323,21 @@ __global__ __launch_bounds__(kT) void fit_fast_kernel(const float* __restrict__ 
   const uint64_t st0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
-  // ---- 1. bracket from a strided sample (position of sample i: the middle of the i-th of kSample equal parts);
-  // every workgroup of the column computes the same one.  The sample's loads go out FIRST (loads return in issue
-  // order: behind the slice's loads below the bracket would wait for the whole slice).
+  // ---- 1. bracket from a sample of kSample values taken as 256 RUNS of 16 consecutive values (one 64-byte line each,
+  // run r around the middle of the r-th of 256 equal parts); every workgroup of the column computes the same one.
+  // Round 3 took 4096 single values n / 4096 apart: 4096 lines of 64 B per workgroup and column for 16 KB of values —
+  // the memory side moved 41 MB per launch for 28 MB of columns (PMC; profiles/hbm_traffic.json reported 55 MB because it
+  // doubles FETCH_SIZE, which is right for 16-byte streaming loads and wrong for these dword gathers).  Runs cost 256 lines.
+  // The bracket is a guess either way — verified below, never trusted: data arranged against the runs (or locally
+  // correlated enough to fool them) takes the exact whole-column select.  The sample's loads go out FIRST (loads return
+  // in issue order: behind the slice's loads below the bracket would wait for the whole slice).
   uint32_t skey[kSample / kT];
 #pragma unroll
   for (int j = 0; j < kSample / kT; ++j) {
     const int64_t i = tid + j * kT;
-    skey[j] = col_key(((2 * i + 1) * n) >> 13);      // / (2 * kSample)
+    const int64_t centre = ((2 * (i >> 4) + 1) * n) >> 9;          // / (2 * 256 runs)
+    const int64_t pos = (centre & ~static_cast<int64_t>(15)) + (i & 15);
+    skey[j] = col_key(pos < n ? pos : n - 1);
   }
   // this workgroup's slice: head (to 16-byte alignment), 16-byte body split over the slices, tail — every element
   // exactly once.  The first batch of the slice's loads is issued NOW: the data does not depend on the bracket,

@@ -100,16 +100,23 @@ constexpr int any_level(int units) {            // 0: the narrowest rows of a un
   return 1;
 }
 constexpr int any_rows(int u, int nq, int level) {
+#ifdef DEWI_ANY_NQ4_OLD
   if (nq >= 4) {                     // four queries behind every row: the arithmetic hides more of the latency
     if (u == 1) return level == 0 ? 6 : 4;
     if (u <= 3) return 2;
     return 1;
   }
+#endif
   if (u == 1) return level == 0 ? 12 : 8;
   if (u == 2) return level == 0 ? 6 : (level == 1 ? 4 : 3);
   if (u == 3) return 2;
   if (u == 4) return level == 0 ? 2 : 1;
   return 1;
+}
+// most queries one corpus pass serves besides 1 (launch_any_long instantiates exactly these)
+constexpr int any_nq_max(int elem_bytes, int u_pad) {
+  if (elem_bytes == 2) return u_pad <= 4 ? 4 : (u_pad <= 8 ? 2 : 1);
+  return u_pad <= 8 ? 4 : 2;
 }
 constexpr int kAnyShortRows = DEWI_ANY_RSHORT;   // loads (of 64 / P rows each) a wave of the short-row kernel keeps in flight
 
@@ -376,19 +383,29 @@ static hipError_t launch_any_long(const ScanPlan& plan, const u32x4* E, int64_t 
       if (plan.level == 2) { DEWI_ANY_LAUNCH(UU, any_rows(UU, NQ, 2)) }                                         \
     }                                                                                                           \
     DEWI_ANY_LAUNCH(UU, any_rows(UU, NQ, 1))
-  if constexpr (NQ == 1 || NQ == 4) {
+  // Queries per pass by row width (the fragments of NQ queries must fit the registers next to the rows in flight): an fp32
+  // unit keeps 4 registers per query, a bf16 unit 4 (cosine, packed pairs) or 8 (l2) — any_nq_max() is the same table
+  constexpr bool kNarrow = ELEM == 0 ? (NQ == 1 || NQ == 4) : true;     // units per lane 1 .. 4 (bf16) / 1 .. 8 (fp32)
+  constexpr bool kMiddle = ELEM == 0 ? (NQ == 1 || NQ == 4) : (NQ == 1 || NQ == 2);   // 5 .. 8
+  constexpr bool kWide = ELEM == 0 ? (NQ == 1 || NQ == 2) : NQ == 1;    // 10 .. 16
+  if constexpr (kNarrow && NQ != 2) {
     switch (plan.u_pad) {
       DEWI_ANY_CASE(1)
       DEWI_ANY_CASE(2)
       DEWI_ANY_CASE(3)
       DEWI_ANY_CASE(4)
+      default: break;
+    }
+  }
+  if constexpr (kMiddle) {
+    switch (plan.u_pad) {
       DEWI_ANY_CASE(5)
       DEWI_ANY_CASE(6)
       DEWI_ANY_CASE(8)
       default: break;
     }
   }
-  if constexpr (NQ == 1 || NQ == 2) {   // wide rows: the fragments of two queries fill the registers
+  if constexpr (kWide) {
     switch (plan.u_pad) {
       DEWI_ANY_CASE(10)
       DEWI_ANY_CASE(12)

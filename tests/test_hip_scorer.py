@@ -133,6 +133,9 @@ def test_fast_fit_adversarial_columns_stay_exact(n):
     stride = n // 8192
     periodic = rs.randn(n).astype(np.float32)
     periodic[(np.arange(8192) * 2 + 1) * n // (2 * 8192)] = 1e6           # every SAMPLED position holds an outlier
+    runs = rs.randn(n).astype(np.float32)                                 # round 4: the sample is 256 runs of 16 values
+    run_start = (((2 * np.arange(256) + 1) * n) >> 9) & ~15
+    runs[np.minimum((run_start[:, None] + np.arange(16)[None, :]).ravel(), n - 1)] = -1e6   # every sampled value an outlier
     heavy_zero = np.where(rs.rand(n) < 0.7, 0.0, rs.gamma(2, 0.5, n)).astype(np.float32)   # 70 % ties at the median
     few_values = rs.choice(np.array([0.25, 0.5, 0.75], np.float32), n)     # three distinct values: lo == hi likely
     bimodal = np.where(np.arange(n) % 2 == 0, rs.randn(n) - 50, rs.randn(n) + 50).astype(np.float32)   # empty middle
@@ -140,6 +143,8 @@ def test_fast_fit_adversarial_columns_stay_exact(n):
         "sorted_up": np.sort(rs.randn(n).astype(np.float32)),
         "sorted_down": np.sort(rs.randn(n).astype(np.float32))[::-1].copy(),
         "periodic_outliers": periodic,
+        "outliers_on_the_sampled_runs": runs,
+        "slow_drift": (np.linspace(-3, 3, n) + 0.01 * rs.randn(n)).astype(np.float32),   # runs of near-equal values
         "heavy_zero": heavy_zero,
         "few_values": few_values,
         "constant": np.full(n, 3.25, np.float32),
