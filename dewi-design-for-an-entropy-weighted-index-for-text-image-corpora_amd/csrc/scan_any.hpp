@@ -95,7 +95,8 @@ constexpr int kAnyLevels = 3;
 constexpr int any_level(int units) {            // 0: the narrowest rows of a units-per-lane count ... 2: the widest
   const int u = (units + 63) / 64;
   if (u == 1) return units <= 40 ? 0 : 1;                        // 528-640 B : 656-1024 B
-  if (u == 2) return units <= 72 ? 0 : (units <= 96 ? 1 : 2);    // 1040-1152 B : 1168-1536 B : 1552-2048 B
+  if (u == 2) return units <= 72 ? 0 : (units <= 92 ? 1 : 2);    // 1040-1152 B : 1168-1472 B : 1488-2048 B (1408 B: 4 rows 6.98 TB/s,
+                                                                 // 3 rows 6.86; 1424 B: 6.97 / 6.92; 1536 B: 6.95 / 7.07)
   if (u == 4) return units <= 224 ? 0 : 1;                       // 3088-3584 B : 3600-4096 B
   return 1;
 }

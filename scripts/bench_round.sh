@@ -6,12 +6,18 @@
 # step: pre-selection over the shadow + exact re-scoring; the one-query leg is an extra line, not the headline), and the
 # single-GPU rehearsal of the sharded loop.
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/bench_$TAG
 mkdir -p $OUT
 run() { local name=$1; shift; python3 bench.py "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err || { tail -20 $OUT/bench_$name.err; exit 1; }; cut -c1-260 $OUT/bench_$name.json; }
 run c2
 run c2_steps20 --steps 20 --warmup 5
+run c2_steps20_condition0 --steps 20 --warmup 5 --condition-ms 0
+# other embedding widths at equal corpus bytes (~3 GB, one query per step): the any-width row kernels
+for d in 128 384 1000 1280 3072; do
+  run dim$d --dim $d --docs $(( 3072000000 / (4 * d) )) --cpu-queries 0
+done
+run dim384_batch4 --dim 384 --docs 2000000 --batch 4 --cpu-queries 0
 run c3 --config c3
 run c4 --config c4
 run c5 --config c5

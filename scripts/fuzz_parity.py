@@ -35,7 +35,10 @@ ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--big", action="store_true", help="corpora of 64K-160K rows at matrix-core dims, batches up to 300: the batched passes")
 args = ap.parse_args()
 rs = np.random.RandomState(args.seed)
-DIMS = [1, 3, 8, 17, 64, 100, 128, 256, 300, 384, 512, 768, 1024, 1536]
+# (round 4: every kind of row kernel — lanes sharing a short row, one row per step with a predicated tail at every
+# instantiated units-per-lane count for fp32 and bf16, the scalar-capable generic kernel, the tuned dim = 256 U ones)
+DIMS = [1, 3, 4, 8, 12, 17, 36, 64, 100, 128, 132, 200, 252, 256, 260, 300, 384, 512, 640, 768, 1000, 1024, 1280, 1536, 1792, 2048,
+        2304, 3072, 4096]
 fails, done = [], {"search": 0, "shards": 0, "fit": 0}
 LAST = {}
 
