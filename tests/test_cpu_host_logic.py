@@ -253,11 +253,12 @@ def test_bench_plain_gpus_n_reaches_the_launcher():
 
 
 def test_profiles_readme_block_matches_the_committed_files():
-    """profiles/r03/README.md ends with a block generated from bench_*.json / kernel_stats_*.csv (scripts/profiles_table.py):
+    """profiles/r03/README.md and profiles/r04/README.md end with a block generated from bench_*.json / kernel_stats_*.csv (scripts/profiles_table.py):
     it must be what those files say now."""
     import subprocess
     import sys
     from pathlib import Path
     repo = Path(__file__).resolve().parent.parent
-    rc = subprocess.run([sys.executable, str(repo / "scripts" / "profiles_table.py"), "r03", "--check"], cwd=repo).returncode
-    assert rc == 0, "profiles/r03/README.md: run `python scripts/profiles_table.py r03`"
+    for tag in ("r03", "r04"):
+        rc = subprocess.run([sys.executable, str(repo / "scripts" / "profiles_table.py"), tag, "--check"], cwd=repo).returncode
+        assert rc == 0, f"profiles/{tag}/README.md: run `python scripts/profiles_table.py {tag}`"
