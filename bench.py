@@ -443,10 +443,12 @@ def run_c2(args, torch, dist, eng, nat, rank, world, device):
     # --batch > 32: the 256-query pass over the bf16 shadow (one per 256 queries)
     # --batch 1 --shadow 1 (cut of at most 32 rows): the bf16 ROW kernel over the shadow
     # (the library names the row kernel of this width itself: the tuned dim = 256 U kernels, the any-width ones, the generic)
-    kernel = (corpus.scan_kernel_name(B, k) if (B < 5 and not shadowed) else f"mfma_scan_f32<false,{args.dim // 256},false,false>" if not shadowed
+    depth_args = f"{-(-args.dim // 256)},false,false,{'true' if args.dim % 256 else 'false'}"   # chunks, SAMPLE, L2, partial last chunk
+    lib_name = corpus.scan_kernel_name(B, k)       # what the library's plan says streams the corpus for this shape
+    kernel = ((f"mfma_scan_f32<false,{depth_args}>" if lib_name.startswith("mfma_scan_f32") else lib_name) if not shadowed
               else f"mfma_scan_bf16_s16<{args.dim // 16},false>" if B > 32
               else f"scan_rows_bf16<{args.dim // 256},1,0,1,true>" if (B == 1 and c <= 32 and args.dim <= 1024)   # (no bf16 row kernel at 1536)
-              else f"mfma_scan_f32<true,{args.dim // 256},false,false>")
+              else f"mfma_scan_f32<true,{depth_args}>")
     traffic, traffic_note = recorded_traffic(f"{n_local}x{args.dim}x{elem}xB{B}", kernel)
     if traffic is None and shadowed and B < 32 and kernel.startswith("mfma_scan_f32"):
         # the depth-split pass is one launch of the same grid over the same rows for 1..32 active queries: the counter record

@@ -156,19 +156,27 @@ __device__ __forceinline__ void split3(const u32x4f& x0, const u32x4f& x1, u32x4
 // L2: the score is -||e - q||^2 (reference backends.py:434-436) in the form 2<e,q> - ||e||^2 - ||q||^2: Qn holds the raw
 //     (bf16 corpus: bf16-rounded) queries, qn2 their squared norms, and ||e||^2 is summed here from the very fragments
 //     that are multiplied (see "row norms" below).
-template <bool BF16, int CH, bool SAMPLE, bool L2>
+// PARTIAL (round 4): the row's LAST chunk holds only 32 * vw of its 256 columns (dim = 256 (CH - 1) + 32 vw, vw = 1..7), so
+//     that every dim % 32 == 0 takes this pass, not only whole chunks.  Wave w multiplies columns [32 w, 32 w + 32) of a chunk:
+//     in the last chunk the waves w >= vw have nothing of this row — they still move their DMA pieces (a piece of the partial
+//     chunk carries the head of the NEXT row behind the row's tail; past the tile's last row the buffer descriptor returns
+//     zeros) and keep every barrier, but skip their matrix instructions: a NaN in the neighbouring row must not reach this
+//     row's score through a 0 x NaN product.  Row stride and query stride become run-time values.  Cosine only (an l2 batch at
+//     such a width would need the exact re-scoring at that width: it takes the row kernels).
+template <bool BF16, int CH, bool SAMPLE, bool L2, bool PARTIAL = false>
 __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __restrict__ E, int64_t n_rows,
                                                                 const void* __restrict__ Qn, int64_t n_tiles,
                                                                 int64_t tile_stride, const float* __restrict__ thr,
                                                                 uint64_t* __restrict__ out, int64_t out_stride,
                                                                 uint32_t* __restrict__ cnt, int n_active,
-                                                                const float* __restrict__ qn2, float aux) {
+                                                                const float* __restrict__ qn2, float aux, int vw) {
   // aux: l2 — the error bound per unit of ||e||^2 + ||q||^2 (exact-refine mode, 0 = unrefined); cosine — a bias subtracted
   // from every threshold (0, or two error bounds when the pass pre-selects over the bf16 shadow of an fp32 corpus)
 #if defined(__HIP_DEVICE_COMPILE__)
   const float l2_margin = L2 ? aux : 0.f;
   using G = DepthGeo<BF16>;
-  constexpr int DIM = CH * kF32ChunkCols;
+  static_assert(!(PARTIAL && L2), "partial last chunk: cosine only");
+  const int DIM = PARTIAL ? (CH - 1) * kF32ChunkCols + 32 * vw : CH * kF32ChunkCols;   // compile-time unless PARTIAL
   constexpr int RM = G::kRing - 1;                             // ring slot of chunk g: g & RM
   extern __shared__ __attribute__((aligned(16))) char lds[];   // ring | partial sums | per-query counters
   float* const red = reinterpret_cast<float*>(lds + G::kRing * G::kChunk);
@@ -187,10 +195,12 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
 #pragma unroll
   for (int ch = 0; ch < CH; ++ch) {
     u32x4f raw[G::kReads];
+    const bool dead = PARTIAL && ch == CH - 1 && w >= vw;      // wave-uniform: no columns of the row in this wave's slice
 #pragma unroll
     for (int m = 0; m < G::kReads; ++m) {
       const char* qrow = static_cast<const char*>(Qn) + static_cast<int64_t>(r) * DIM * G::kElem;
-      raw[m] = *reinterpret_cast<const u32x4f*>(qrow + kF32ChunkCols * G::kElem * ch + 32 * G::kElem * w + 16 * (2 * m + h));
+      raw[m] = u32x4f{0u, 0u, 0u, 0u};
+      if (!dead) raw[m] = *reinterpret_cast<const u32x4f*>(qrow + kF32ChunkCols * G::kElem * ch + 32 * G::kElem * w + 16 * (2 * m + h));
     }
     if constexpr (kSplit) {
       split3(raw[0], raw[1], qf[ch][0], qf[ch][1], qf[ch][2]);
@@ -217,7 +227,7 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
   //   fp32: piece p (0..3) of a wave is row w + 8 p (one row = 64 units); row & 15 is w for p even, w + 8 for p odd.
   //   bf16: piece p (0..1) is rows 2 (w + 8 p) and + 1 (32 units each; lanes 32.. take the second row);
   //         row & 15 = (2 w + lane / 32) & 15 for both pieces.
-  const uint32_t row_bytes = DIM * G::kElem;
+  const uint32_t row_bytes = static_cast<uint32_t>(DIM) * G::kElem;
   const uint32_t row_b = static_cast<uint32_t>(2 * w + (lane >> 5));
   const uint32_t voff_even = BF16 ? row_b * row_bytes + 16u * (static_cast<uint32_t>(lane & 31) ^ (row_b & 15u))
                                   : static_cast<uint32_t>(w) * row_bytes + 16u * static_cast<uint32_t>(lane ^ w);
@@ -255,8 +265,22 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
   //   Chunk g+4 refills the slot of chunk g, which every wave has finished reading before the barrier of
   //   iteration g.  Chunks past the last tile are fetched through an empty descriptor (zeros, no memory traffic)
   //   so that every iteration has the same 12 pieces outstanding at its vmcnt(8).
+  // PARTIAL: in the row's last chunk only the lanes whose SOURCE unit lies inside the row fetch (EXEC-masked DMA: the other
+  // lanes move nothing and leave their LDS bytes as they are — only the waves that skip the chunk would read those).  Without the
+  // mask a piece carried the head of the next row behind the row's tail: dim 128 moved every byte twice (pass 0.91 ms per 3 GB).
+  const uint32_t valid_units = PARTIAL ? static_cast<uint32_t>(vw) * (BF16 ? 4u : 8u) : 64u;
+  const bool in_row_even = BF16 ? ((static_cast<uint32_t>(lane & 31) ^ (row_b & 15u)) < valid_units)
+                                : (static_cast<uint32_t>(lane ^ w) < valid_units);
+  const bool in_row_odd = BF16 ? in_row_even : (static_cast<uint32_t>(lane ^ (w + 8)) < valid_units);
   auto issue_piece = [&](__amdgpu_buffer_rsrc_t rsrc, int ch, int slot, int p) {
     char* base = lds + slot * G::kChunk + w * 1024;        // piece w + 8 p of the chunk's 1 KiB pieces
+    if (PARTIAL && ch == CH - 1) {
+      if ((p & 1) ? in_row_odd : in_row_even)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtrF)(base + p * 8 * 1024), 16, (p & 1) ? voff_odd : voff_even,
+                                                 p * (BF16 ? 16 : 8) * static_cast<int>(row_bytes) + ch * G::kRowChunk, 0,
+                                                 DEWI_F32MFMA_DMA_AUX);
+      return;
+    }
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtrF)(base + p * 8 * 1024), 16, (p & 1) ? voff_odd : voff_even,
                                              p * (BF16 ? 16 : 8) * static_cast<int>(row_bytes) + ch * G::kRowChunk, 0,
                                              DEWI_F32MFMA_DMA_AUX);
@@ -535,7 +559,12 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
       const __amdgpu_buffer_rsrc_t rs4 = tile_rsrc(it + (ch + G::kRing) / CH);
       __builtin_amdgcn_sched_barrier(0);
       const f32x16f zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if constexpr (kSplit) {
+      const bool skip = PARTIAL && ch == CH - 1 && w >= vw;   // wave-uniform (PARTIAL: see the kernel's header)
+      if (skip) {
+        if (ch == 0) acc = zero;                              // a one-chunk row: this wave contributes nothing at all
+#pragma unroll
+        for (int p = 0; p < G::kPieces; ++p) issue_piece(rs4, (ch + G::kRing) % CH, static_cast<int>((g + G::kRing) & RM), p);
+      } else if constexpr (kSplit) {
         // two groups of 8 columns: the cut (36 vector instructions) and six MFMAs each; the DMA pieces go out behind
         // the third and sixth MFMA of a group
 #pragma unroll
@@ -635,11 +664,16 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
 float depth_l2_margin(int dim) { return 2.f * static_cast<float>(dim) * 1.1920929e-7f; }   // 2 dim 2^-23
 
 bool mfma_f32_path_supported(int elem_type, int64_t n_rows, int dim, int n_queries, int n_candidates, int space) {
-  const int ch = dim / kF32ChunkCols;
   const int min_q = elem_type ? kMfmaMinQueries : kMfmaF32MinQueries;
+  if ((space != DEWI_SPACE_COSINE && space != DEWI_SPACE_L2) || n_queries < min_q || n_rows < 64 * 1024 || n_candidates > 256 || dim <= 0)
+    return false;
+  if (dim % kF32ChunkCols != 0) {
+    // a partial last chunk (round 4): any dim % 32 == 0 up to 1024 columns, cosine
+    return space == DEWI_SPACE_COSINE && dim % 32 == 0 && dim < 4 * kF32ChunkCols;
+  }
+  const int ch = dim / kF32ChunkCols;
   if (space == DEWI_SPACE_L2 && elem_type == 0 && ch > kF32MaxL2Chunks) return false;   // fp32 rows beyond 768 columns: query pieces + row norms do not fit the registers
-  return (space == DEWI_SPACE_COSINE || space == DEWI_SPACE_L2) && n_queries >= min_q && dim % kF32ChunkCols == 0 && ch >= 1 &&
-         ch <= 6 && ch != 5 && n_rows >= 64 * 1024 && n_candidates <= 256;
+  return ch >= 1 && ch <= 6 && ch != 5;
 }
 
 MfmaF32Layout plan_mfma_f32(int elem_type, int64_t n_rows, int dim, int n_queries, int n_candidates, int compute_units,
@@ -676,20 +710,21 @@ MfmaF32Layout plan_mfma_f32(int elem_type, int64_t n_rows, int dim, int n_querie
   return m;
 }
 
-template <bool BF16, int CH, bool L2>
+// PARTIAL: dim = 256 (CH - 1) + 32 vw (see the kernel); otherwise dim = 256 CH and vw is ignored
+template <bool BF16, int CH, bool L2, bool PARTIAL = false>
 static hipError_t run_mfma_f32_dim(const MfmaF32Layout& m, const void* E, int64_t n_rows, int n_queries, int n_candidates,
-                                   char* ws, hipStream_t stream, float thr_bias) {
+                                   char* ws, hipStream_t stream, float thr_bias, int vw = 8) {
   // l2 over an fp32 corpus runs in exact-refine mode (see stage2_finish and select_rerank.hip): error bound per unit of
   // ||e||^2 + ||q||^2.  bf16 corpora (opt-in, approximate) and cosine: no margin.
   const float l2_margin = L2 ? (BF16 ? 0.f : depth_l2_margin(CH * kF32ChunkCols)) : thr_bias;   // the kernel's `aux`
-  constexpr int DIM = CH * kF32ChunkCols;
+  const int DIM = PARTIAL ? (CH - 1) * kF32ChunkCols + 32 * vw : CH * kF32ChunkCols;
   constexpr int kLds = depth_lds_bytes<BF16>();
   static PerDeviceOnce attr_once;   // one per instantiation
   const hipError_t ea = attr_once.run([] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan_f32<BF16, CH, true, L2>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan_f32<BF16, CH, true, L2, PARTIAL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan_f32<BF16, CH, false, L2>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan_f32<BF16, CH, false, L2, PARTIAL>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
   });
   if (ea != hipSuccess) return ea;
@@ -707,17 +742,17 @@ static hipError_t run_mfma_f32_dim(const MfmaF32Layout& m, const void* E, int64_
     const int n_active = n_queries - g * kF32Queries < kF32Queries ? n_queries - g * kF32Queries : kF32Queries;
     // 1. group maxima over the strided sample
     const float* q2g = qn2 + g * kF32Queries;
-    hipLaunchKernelGGL((mfma_scan_f32<BF16, CH, true, L2>), dim3(m.sample_blocks), dim3(kF32Threads), kLds, stream, E, n_rows, qg,
+    hipLaunchKernelGGL((mfma_scan_f32<BF16, CH, true, L2, PARTIAL>), dim3(m.sample_blocks), dim3(kF32Threads), kLds, stream, E, n_rows, qg,
                        m.n_sample_tiles, m.tile_stride, static_cast<const float*>(nullptr), reinterpret_cast<uint64_t*>(dense),
-                       m.sample_stride, static_cast<uint32_t*>(nullptr), n_active, q2g, l2_margin);
+                       m.sample_stride, static_cast<uint32_t*>(nullptr), n_active, q2g, l2_margin, vw);
     // 2. per-query threshold: the c-th largest group maximum (real queries only)
     const hipError_t et = launch_sample_threshold(dense, m.sample_stride, m.sample_stride, n_candidates, tg, n_active, stream);
     if (et != hipSuccess) return et;
     // 3. the full pass with the filter (the kernel dewi_timing_read reports: algorithmic bytes = n_rows * dim * elem)
     timing_begin(stream);
-    hipLaunchKernelGGL((mfma_scan_f32<BF16, CH, false, L2>), dim3(m.n_blocks), dim3(kF32Threads), kLds, stream, E, n_rows, qg,
+    hipLaunchKernelGGL((mfma_scan_f32<BF16, CH, false, L2, PARTIAL>), dim3(m.n_blocks), dim3(kF32Threads), kLds, stream, E, n_rows, qg,
                        m.n_tiles, static_cast<int64_t>(1), static_cast<const float*>(tg), og, static_cast<int64_t>(m.seg_cap), cg,
-                       n_active, q2g, l2_margin);
+                       n_active, q2g, l2_margin, vw);
     timing_end(stream);
   }
   return hipGetLastError();
@@ -745,6 +780,22 @@ hipError_t launch_mfma_f32(const MfmaF32Layout& m, int elem_type, const void* d_
     }                                                                                                                        \
     return elem_type ? run_mfma_f32_dim<true, CH, false>(m, d_E, n_rows, n_queries, n_candidates, ws, stream, thr_bias)      \
                      : run_mfma_f32_dim<false, CH, false>(m, d_E, n_rows, n_queries, n_candidates, ws, stream, thr_bias);
+  if (dim % kF32ChunkCols != 0) {      // a partial last chunk: cosine, up to four chunks (mfma_f32_path_supported)
+    if (l2 || dim % 32 != 0) return hipErrorInvalidValue;
+    const int vw = (dim % kF32ChunkCols) / 32;
+#define DEWI_DEPTH_PARTIAL(CH)                                                                                                  \
+  case CH:                                                                                                                      \
+    return elem_type ? run_mfma_f32_dim<true, CH, false, true>(m, d_E, n_rows, n_queries, n_candidates, ws, stream, thr_bias, vw) \
+                     : run_mfma_f32_dim<false, CH, false, true>(m, d_E, n_rows, n_queries, n_candidates, ws, stream, thr_bias, vw);
+    switch (dim / kF32ChunkCols + 1) {
+      DEWI_DEPTH_PARTIAL(1)
+      DEWI_DEPTH_PARTIAL(2)
+      DEWI_DEPTH_PARTIAL(3)
+      DEWI_DEPTH_PARTIAL(4)
+      default: return hipErrorInvalidValue;
+    }
+#undef DEWI_DEPTH_PARTIAL
+  }
   switch (dim / kF32ChunkCols) {
     DEWI_DEPTH(1)
     DEWI_DEPTH(2)

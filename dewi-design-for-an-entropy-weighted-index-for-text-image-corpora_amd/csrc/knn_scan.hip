@@ -517,15 +517,18 @@ static hipError_t launch_flagged_s(const ScanPlan& plan, const float* E, int64_t
 }
 
 bool scan_flagged_supported(const ScanPlan& plan, int elem_bytes) {
+  (void)elem_bytes;
   if (plan.kind == kScanFast) return true;
-  // any-width kernels: the widths the matrix-core passes of a bf16 corpus run at outside the dim = 256 U set
-  // (128, 384, 640: the 256-query pass; 1536: the depth-split pass)
-  return elem_bytes == 2 && (plan.kind == kScanAnyShort || (plan.kind == kScanAnyLong && plan.u_pad <= 3));
+  // any-width kernels: the widths the matrix-core passes run at outside the dim = 256 U set — dim % 32 == 0 up to 1024
+  // columns (the depth-split pass with a partial last chunk), bf16 128 / 384 / 640 (the 256-query pass) and 1536
+  return plan.kind == kScanAnyShort || (plan.kind == kScanAnyLong && plan.u_pad <= 4);
 }
 
 hipError_t launch_scan_flagged_f32(const ScanPlan& plan, const float* d_E, int64_t n_rows, int dim, const float* d_q_raw,
                                    int n_queries, int n_candidates, int space, uint64_t* d_keys, const uint32_t* d_flags,
                                    hipStream_t stream) {
+  if (plan.kind == kScanAnyLong || plan.kind == kScanAnyShort)
+    return launch_scan_any_flagged_f32(plan, d_E, n_rows, dim, d_q_raw, n_queries, n_candidates, space, d_keys, d_flags, stream);
   if (plan.kind != kScanFast) return hipErrorInvalidValue;
 #define DEWI_FLAGGED(UU)                                                                                                 \
   case UU:                                                                                                               \

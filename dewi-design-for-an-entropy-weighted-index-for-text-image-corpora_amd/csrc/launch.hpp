@@ -117,6 +117,9 @@ hipError_t launch_scan_flagged_f32(const ScanPlan& plan, const float* d_E, int64
 hipError_t launch_scan_flagged_bf16(const ScanPlan& plan, const uint16_t* d_E, int64_t n_rows, int dim, const float* d_q_raw,
                                     int n_queries, int n_candidates, int space, uint64_t* d_keys, const uint32_t* d_flags,
                                     hipStream_t stream);
+hipError_t launch_scan_any_flagged_f32(const ScanPlan& plan, const float* d_E, int64_t n_rows, int dim, const float* d_q_raw,
+                                       int n_queries, int n_candidates, int space, uint64_t* d_keys, const uint32_t* d_flags,
+                                       hipStream_t stream);
 hipError_t launch_scan_any_flagged_bf16(const ScanPlan& plan, const uint16_t* d_E, int64_t n_rows, int dim, const float* d_q_raw,
                                         int n_queries, int n_candidates, int space, uint64_t* d_keys, const uint32_t* d_flags,
                                         hipStream_t stream);

@@ -45,7 +45,8 @@ LAST = {}
 
 def one_search_case(i):
     if args.big:
-        dim = int(rs.choice([128, 256, 256, 384, 512, 512, 640, 768, 768, 768, 1024, 1536]))
+        # (round 4: widths with a partial last chunk on the depth-split pass — 96, 160, 320, 384, 640, 896, 992)
+        dim = int(rs.choice([96, 128, 160, 256, 256, 320, 384, 384, 512, 512, 640, 768, 768, 768, 896, 992, 1024, 1536]))
         n = int(rs.randint(65_536, 160_000))
         bf16 = bool(rs.rand() < 0.45)
         space = "l2" if rs.rand() < 0.2 else "cosine"

@@ -54,7 +54,10 @@ def _corpus(n, dim, seed, space="cosine"):
                                        # up to 32 queries, and dimensions the 256-query kernel cannot hold in
                                        # registers: the depth-split pass (csrc/knn_mfma_f32.hip, bf16 geometry)
                                        (768, 70_001, 8, 10), (768, 70_001, 32, 100), (512, 80_000, 2, 10),
-                                       (1024, 65_600, 70, 10), (1536, 66_000, 40, 10)])
+                                       (1024, 65_600, 70, 10), (1536, 66_000, 40, 10),
+                                       # round 4: the depth-split pass with a PARTIAL last chunk (dim % 32 == 0, not % 256)
+                                       (384, 70_000, 8, 10), (96, 131_072, 12, 10), (640, 66_000, 32, 10), (992, 65_600, 5, 10),
+                                       (160, 70_001, 70, 100)])
 def test_mfma_batched_vs_oracle(dim, n, b, k):
     import torch
     cb, Eb, dewi32, ent32 = _corpus(n, dim, seed=dim + b)

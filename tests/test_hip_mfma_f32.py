@@ -45,7 +45,10 @@ def _corpus(n, dim, seed):
 
 @pytest.mark.parametrize("dim,n,b,k", [(768, 70_001, 32, 10), (768, 66_000, 5, 10), (512, 80_000, 70, 10),
                                        (256, 131_073, 33, 100), (1024, 65_536, 8, 10), (1536, 65_600, 17, 10),
-                                       (768, 300_000, 64, 128)])
+                                       (768, 300_000, 64, 128),
+                                       # round 4: a PARTIAL last chunk — any dim % 32 == 0 up to 1024 columns takes the pass
+                                       (384, 70_001, 32, 10), (640, 66_000, 12, 10), (96, 100_000, 7, 10), (992, 65_600, 33, 10),
+                                       (160, 70_000, 64, 100), (32, 66_000, 5, 10)])
 def test_mfma_f32_batched_vs_oracle(dim, n, b, k):
     import torch
     from dewi import _engine as eng
@@ -104,6 +107,35 @@ def test_mfma_f32_a_batch_of_four_stays_on_the_scan_kernels_and_agrees():
     ids4 = np.concatenate([c.search(Q[i:i + 4], 10, 0.3, 0.0)[0] for i in (0, 4, 8)])
     assert np.mean(ids4 == ids12) > 0.98
     check_batch(E, Q, dewi32, ent32, 10, 0.3, 0.0, "cosine", ids12, sc12, exact_gaps=False)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("dim", [384, 96, 800])
+def test_partial_chunk_keeps_a_nan_row_out_of_its_neighbours(dim, bf16):
+    """dim % 256 != 0: the DMA piece of a row's partial last chunk carries the head of the NEXT row; the waves whose columns
+    lie past the row skip their matrix instructions, so a NaN row (a zero embedding: 0/0, as in the reference) must not turn
+    the row stored in front of it into NaN.  The NaN row itself ranks first for every query (NumPy's partition order)."""
+    from dewi import _engine as eng
+    import torch
+    n, k, b = 70_000, 5, 16
+    raw = orc.synth_corpus(n, dim, seed=dim)
+    bad = [1000, 31 + 32 * 7, n - 1]                   # mid-tile, last row of a tile, last row of the corpus
+    for i in bad:
+        raw[i] = 0.0
+    cols = orc.synth_payload_columns(n, seed=dim)
+    c = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"])
+    if bf16:
+        c = c.to_bf16()
+    assert c.scan_kernel_name(b, k).startswith("mfma_scan_f32")
+    Q = orc.synth_queries(b, dim, seed=3)
+    Q[0], Q[1], Q[2] = raw[999], raw[30 + 32 * 7], raw[n - 2]        # the rows stored right in front of the NaN rows
+    ids, sc = (t.cpu().numpy() for t in c.search_device(torch.from_numpy(Q).cuda(), k, 0.0, 0.0))
+    assert all(sorted(row[:3].tolist()) == sorted(bad) for row in ids) and np.isnan(sc[:, :3]).all()   # NaN rows first
+    assert not np.isnan(sc[:, 3:]).any()
+    assert ids[0, 3] == 999 and ids[1, 3] == 30 + 32 * 7 and ids[2, 3] == n - 2
+    assert np.allclose(sc[:3, 3], 1.0, atol=1e-2 if bf16 else 1e-5)
+    one = [c.search_device(torch.from_numpy(Q[j:j + 1]).cuda(), k, 0.0, 0.0)[0].cpu().numpy()[0] for j in range(b)]
+    assert np.mean(np.stack(one) == ids) > 0.95        # the row kernels agree up to near-tie swaps
 
 
 def test_mfma_f32_overflow_is_repaired_behind_the_c_abi():
