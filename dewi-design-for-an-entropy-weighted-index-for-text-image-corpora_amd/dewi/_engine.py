@@ -266,8 +266,11 @@ class DeviceCorpus:
         torch = _torch()
         with self._lock, torch.cuda.device(self.device):
             q = self.stage_queries(queries)
-            # Results come back through cached device + pinned host buffers: one async copy and ONE stream
-            # synchronisation instead of two blocking pageable copies.
+            # Small result sets (one query, a handful: what the reference's search returns) are written by the select kernel
+            # STRAIGHT INTO pinned host memory (device-visible at its own address on ROCm; 12 bytes per result over PCIe): no
+            # device buffer, no copy command, ONE stream synchronisation — 3.5 us less per blocking call than a device
+            # buffer + async D2H copy (round 4: C1 45.4 -> 41.9 us p50, C2 464.0 -> 460.5).  Large batches keep the device
+            # buffer and one DMA copy (tens of thousands of 4- and 8-byte stores over PCIe would cost more than they save).
             b, kk = int(q.shape[0]), max(int(k), 0)
             io = self._io.get((b, kk))
             if io is None:
@@ -275,15 +278,17 @@ class DeviceCorpus:
                     self._io.clear()
                 # ids (int64) and scores (fp32) share one allocation, so that they return in one copy
                 n_el = b * kk
-                dbuf = torch.empty(n_el * 12, dtype=torch.uint8, device=self.device)
                 hbuf = torch.empty(n_el * 12, dtype=torch.uint8, pin_memory=True)
-                io = (dbuf[: n_el * 8].view(torch.int64).view(b, kk), dbuf[n_el * 8:].view(torch.float32).view(b, kk),
+                dbuf = None if n_el <= 4096 else torch.empty(n_el * 12, dtype=torch.uint8, device=self.device)
+                tgt = hbuf if dbuf is None else dbuf
+                io = (tgt[: n_el * 8].view(torch.int64).view(b, kk), tgt[n_el * 8:].view(torch.float32).view(b, kk),
                       hbuf[: n_el * 8].view(torch.int64).view(b, kk), hbuf[n_el * 8:].view(torch.float32).view(b, kk),
                       dbuf, hbuf)
                 self._io[(b, kk)] = io
             if kk > 0:
                 self.search_device(q, k, eta, entropy_pref, io[0], io[1], candidates=candidates, similarity=similarity)
-                io[5].copy_(io[4], non_blocking=True)
+                if io[4] is not None:
+                    io[5].copy_(io[4], non_blocking=True)
                 torch.cuda.current_stream().synchronize()
             ids_h = io[2].numpy().copy()
             scores_h = io[3].numpy().copy()

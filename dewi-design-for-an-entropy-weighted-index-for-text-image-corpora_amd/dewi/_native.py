@@ -190,5 +190,6 @@ def ptr(t) -> int:
     """Device pointer of a contiguous torch tensor (0 for None)."""
     if t is None:
         return 0
-    assert t.is_cuda and t.is_contiguous()
+    # (pinned host tensors are device-visible at their own address on ROCm: result buffers may live there)
+    assert (t.is_cuda or t.is_pinned()) and t.is_contiguous()
     return int(t.data_ptr())
