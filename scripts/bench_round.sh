@@ -18,6 +18,10 @@ for d in 128 384 1000 1280 3072; do
   run dim$d --dim $d --docs $(( 3072000000 / (4 * d) )) --cpu-queries 0
 done
 run dim384_batch4 --dim 384 --docs 2000000 --batch 4 --cpu-queries 0
+# 32 queries per step at widths with a partial last chunk on the depth-split pass (round 4)
+run dim384_batch32 --dim 384 --docs 2000000 --batch 32 --steps 300 --warmup 60 --cpu-queries 0
+run dim640_batch32 --dim 640 --docs 1200000 --batch 32 --steps 300 --warmup 60 --cpu-queries 0
+run dim128_batch32 --dim 128 --docs 6000000 --batch 32 --steps 300 --warmup 60 --cpu-queries 0
 run c3 --config c3
 run c4 --config c4
 run c5 --config c5
