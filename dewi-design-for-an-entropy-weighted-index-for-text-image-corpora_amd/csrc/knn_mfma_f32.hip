@@ -668,12 +668,17 @@ bool mfma_f32_path_supported(int elem_type, int64_t n_rows, int dim, int n_queri
   if ((space != DEWI_SPACE_COSINE && space != DEWI_SPACE_L2) || n_queries < min_q || n_rows < 64 * 1024 || n_candidates > 256 || dim <= 0)
     return false;
   if (dim % kF32ChunkCols != 0) {
-    // a partial last chunk (round 4): any dim % 32 == 0 up to 1024 columns, cosine
-    return space == DEWI_SPACE_COSINE && dim % 32 == 0 && dim < 4 * kF32ChunkCols;
+    // a partial last chunk (round 4): any dim % 32 == 0 up to 1536 columns, cosine
+    return space == DEWI_SPACE_COSINE && dim % 32 == 0 && dim < 6 * kF32ChunkCols;
   }
   const int ch = dim / kF32ChunkCols;
-  if (space == DEWI_SPACE_L2 && elem_type == 0 && ch > kF32MaxL2Chunks) return false;   // fp32 rows beyond 768 columns: query pieces + row norms do not fit the registers
-  return ch >= 1 && ch <= 6 && ch != 5;
+  if (space == DEWI_SPACE_L2) {
+    if (elem_type == 0 && ch > kF32MaxL2Chunks) return false;   // fp32 rows beyond 768 columns: query pieces + row norms do not fit the registers
+    return ch >= 1 && ch <= 6 && ch != 5;
+  }
+  // cosine, whole chunks: 256 ... 1536, 2048 (fp32: the query share of a wave is 16 registers per chunk — eight chunks fit);
+  // a bf16 corpus (8 registers per chunk) also 3072 and 4096
+  return (ch >= 1 && ch <= 6) || ch == 8 || (elem_type == 1 && (ch == 12 || ch == 16));
 }
 
 MfmaF32Layout plan_mfma_f32(int elem_type, int64_t n_rows, int dim, int n_queries, int n_candidates, int compute_units,
@@ -792,18 +797,32 @@ hipError_t launch_mfma_f32(const MfmaF32Layout& m, int elem_type, const void* d_
       DEWI_DEPTH_PARTIAL(2)
       DEWI_DEPTH_PARTIAL(3)
       DEWI_DEPTH_PARTIAL(4)
+      DEWI_DEPTH_PARTIAL(5)
+      DEWI_DEPTH_PARTIAL(6)
       default: return hipErrorInvalidValue;
     }
 #undef DEWI_DEPTH_PARTIAL
   }
+  // cosine-only widths (round 4): 1280, 2048; bf16 corpora also 3072 and 4096
+#define DEWI_DEPTH_COS(CH, ALLOW_F32)                                                                                      \
+  case CH:                                                                                                                   \
+    if (l2) return hipErrorInvalidValue;                                                                                     \
+    if (elem_type) return run_mfma_f32_dim<true, CH, false>(m, d_E, n_rows, n_queries, n_candidates, ws, stream, thr_bias);   \
+    if constexpr (ALLOW_F32) return run_mfma_f32_dim<false, CH, false>(m, d_E, n_rows, n_queries, n_candidates, ws, stream, thr_bias); \
+    return hipErrorInvalidValue;
   switch (dim / kF32ChunkCols) {
     DEWI_DEPTH(1)
     DEWI_DEPTH(2)
     DEWI_DEPTH(3)
     DEWI_DEPTH(4)
+    DEWI_DEPTH_COS(5, true)
     DEWI_DEPTH(6)
+    DEWI_DEPTH_COS(8, true)
+    DEWI_DEPTH_COS(12, false)
+    DEWI_DEPTH_COS(16, false)
     default: return hipErrorInvalidValue;
   }
+#undef DEWI_DEPTH_COS
 #undef DEWI_DEPTH
 }
 

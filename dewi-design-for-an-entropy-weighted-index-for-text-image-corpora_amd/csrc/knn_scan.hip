@@ -519,9 +519,9 @@ static hipError_t launch_flagged_s(const ScanPlan& plan, const float* E, int64_t
 bool scan_flagged_supported(const ScanPlan& plan, int elem_bytes) {
   (void)elem_bytes;
   if (plan.kind == kScanFast) return true;
-  // any-width kernels: the widths the matrix-core passes run at outside the dim = 256 U set — dim % 32 == 0 up to 1024
-  // columns (the depth-split pass with a partial last chunk), bf16 128 / 384 / 640 (the 256-query pass) and 1536
-  return plan.kind == kScanAnyShort || (plan.kind == kScanAnyLong && plan.u_pad <= 4);
+  // any-width kernels: the widths the matrix-core passes run at outside the dim = 256 U set — dim % 32 == 0 up to 1536
+  // columns (the depth-split pass with a partial last chunk), 1280 / 2048, bf16 also 3072 / 4096 (512 units per row)
+  return plan.kind == kScanAnyShort || (plan.kind == kScanAnyLong && plan.u_pad <= 8);
 }
 
 hipError_t launch_scan_flagged_f32(const ScanPlan& plan, const float* d_E, int64_t n_rows, int dim, const float* d_q_raw,

@@ -464,7 +464,7 @@ static hipError_t launch_scan_any_impl(const ScanPlan& plan, const void* d_E, in
   return hipErrorInvalidValue;
 }
 
-// flagged (repair) launches: the middle rows-in-flight level, rows of at most 256 units (see scan_flagged_supported)
+// flagged (repair) launches: the middle rows-in-flight level, rows of at most 512 units (see scan_flagged_supported)
 template <int ELEM, int SPACE, int S>
 static hipError_t launch_any_flagged_s(const ScanPlan& plan, const u32x4* E, int64_t n_rows, const float* Q, int n_queries, int c,
                                        uint64_t* keys, const uint32_t* flags, hipStream_t stream) {
@@ -483,6 +483,9 @@ static hipError_t launch_any_flagged_s(const ScanPlan& plan, const u32x4* E, int
     DEWI_ANY_FLAGGED(2)
     DEWI_ANY_FLAGGED(3)
     DEWI_ANY_FLAGGED(4)
+    DEWI_ANY_FLAGGED(5)
+    DEWI_ANY_FLAGGED(6)
+    DEWI_ANY_FLAGGED(8)
     default: break;
   }
 #undef DEWI_ANY_FLAGGED

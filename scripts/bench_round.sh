@@ -22,6 +22,8 @@ run dim384_batch4 --dim 384 --docs 2000000 --batch 4 --cpu-queries 0
 run dim384_batch32 --dim 384 --docs 2000000 --batch 32 --steps 300 --warmup 60 --cpu-queries 0
 run dim640_batch32 --dim 640 --docs 1200000 --batch 32 --steps 300 --warmup 60 --cpu-queries 0
 run dim128_batch32 --dim 128 --docs 6000000 --batch 32 --steps 300 --warmup 60 --cpu-queries 0
+run dim1280_batch32 --dim 1280 --docs 600000 --batch 32 --steps 300 --warmup 60 --cpu-queries 0
+run dim2048_batch32 --dim 2048 --docs 375000 --batch 32 --steps 300 --warmup 60 --cpu-queries 0
 run c3 --config c3
 run c4 --config c4
 run c5 --config c5

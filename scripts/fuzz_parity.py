@@ -46,7 +46,7 @@ LAST = {}
 def one_search_case(i):
     if args.big:
         # (round 4: widths with a partial last chunk on the depth-split pass — 96, 160, 320, 384, 640, 896, 992)
-        dim = int(rs.choice([96, 128, 160, 256, 256, 320, 384, 384, 512, 512, 640, 768, 768, 768, 896, 992, 1024, 1536]))
+        dim = int(rs.choice([96, 128, 160, 256, 256, 320, 384, 384, 512, 512, 640, 768, 768, 768, 896, 992, 1024, 1280, 1312, 1536, 2048]))
         n = int(rs.randint(65_536, 160_000))
         bf16 = bool(rs.rand() < 0.45)
         space = "l2" if rs.rand() < 0.2 else "cosine"

@@ -9,5 +9,7 @@ r=json.loads(open('$O/bench_$name.json').read().strip().splitlines()[-1]); print
 run dim384_batch32 --dim 384 --docs 2000000 --batch 32 --steps 300 --warmup 60
 run dim640_batch32 --dim 640 --docs 1200000 --batch 32 --steps 300 --warmup 60
 run dim128_batch32 --dim 128 --docs 6000000 --batch 32 --steps 300 --warmup 60
+run dim1280_batch32 --dim 1280 --docs 600000 --batch 32 --steps 300 --warmup 60
+run dim2048_batch32 --dim 2048 --docs 375000 --batch 32 --steps 300 --warmup 60
+run dim1536_batch32 --dim 1536 --docs 500000 --batch 32 --steps 300 --warmup 60
 run c2_batch32 --batch 32 --steps 400 --warmup 100
-run c3 --config c3

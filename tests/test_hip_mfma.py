@@ -57,7 +57,10 @@ def _corpus(n, dim, seed, space="cosine"):
                                        (1024, 65_600, 70, 10), (1536, 66_000, 40, 10),
                                        # round 4: the depth-split pass with a PARTIAL last chunk (dim % 32 == 0, not % 256)
                                        (384, 70_000, 8, 10), (96, 131_072, 12, 10), (640, 66_000, 32, 10), (992, 65_600, 5, 10),
-                                       (160, 70_001, 70, 100)])
+                                       (160, 70_001, 70, 100),
+                                       # ... and the wider whole-chunk rows: 1280, 2048, 3072, 4096 (bf16: 8 query registers per chunk)
+                                       (1280, 65_600, 9, 10), (1312, 65_600, 33, 10), (2048, 65_600, 4, 10), (3072, 65_536, 12, 10),
+                                       (4096, 65_536, 32, 10)])
 def test_mfma_batched_vs_oracle(dim, n, b, k):
     import torch
     cb, Eb, dewi32, ent32 = _corpus(n, dim, seed=dim + b)

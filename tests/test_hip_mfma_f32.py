@@ -48,7 +48,9 @@ def _corpus(n, dim, seed):
                                        (768, 300_000, 64, 128),
                                        # round 4: a PARTIAL last chunk — any dim % 32 == 0 up to 1024 columns takes the pass
                                        (384, 70_001, 32, 10), (640, 66_000, 12, 10), (96, 100_000, 7, 10), (992, 65_600, 33, 10),
-                                       (160, 70_000, 64, 100), (32, 66_000, 5, 10)])
+                                       (160, 70_000, 64, 100), (32, 66_000, 5, 10),
+                                       # ... and 1280 / 2048 columns (whole chunks, fp32 instruction as at 1536), 1312 = five chunks + one wave
+                                       (1280, 66_000, 12, 10), (1312, 65_600, 7, 10), (2048, 65_600, 8, 10)])
 def test_mfma_f32_batched_vs_oracle(dim, n, b, k):
     import torch
     from dewi import _engine as eng
