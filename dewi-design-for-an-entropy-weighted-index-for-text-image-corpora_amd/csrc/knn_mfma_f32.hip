@@ -664,7 +664,12 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
 float depth_l2_margin(int dim) { return 2.f * static_cast<float>(dim) * 1.1920929e-7f; }   // 2 dim 2^-23
 
 bool mfma_f32_path_supported(int elem_type, int64_t n_rows, int dim, int n_queries, int n_candidates, int space) {
-  const int min_q = elem_type ? kMfmaMinQueries : kMfmaF32MinQueries;
+  // Smallest batch that takes the pass.  bf16 corpus: 2.  fp32 corpus, l2 (exact-refine mode: the select re-scores): 5.  fp32 corpus,
+  // cosine (round 4): 2 — the row kernels serve 2 or 3 queries as 2 or 3 corpus passes (0.86 / 1.29 ms at 1 M x 768 against 0.50 for
+  // the pass), and their four-queries-per-pass form is vector-bound on short rows (3 GB at dim 256: 0.92 ms against 0.59); only four
+  // queries over rows of 768 columns or more stay on it (0.47 ms against 0.50).
+  int min_q = elem_type ? kMfmaMinQueries : kMfmaF32MinQueries;
+  if (!elem_type && space == DEWI_SPACE_COSINE) min_q = (n_queries == 4 && dim >= 768) ? kMfmaF32MinQueries : kMfmaMinQueries;
   if ((space != DEWI_SPACE_COSINE && space != DEWI_SPACE_L2) || n_queries < min_q || n_rows < 64 * 1024 || n_candidates > 256 || dim <= 0)
     return false;
   if (dim % kF32ChunkCols != 0) {
