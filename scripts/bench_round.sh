@@ -27,6 +27,9 @@ run dim2048_batch32 --dim 2048 --docs 375000 --batch 32 --steps 300 --warmup 60 
 run c3 --config c3
 run c4 --config c4
 run c5 --config c5
+run c2_batch2 --batch 2 --steps 300 --warmup 60
+run c2_batch3 --batch 3 --steps 300 --warmup 60
+run c2_batch4 --batch 4 --steps 300 --warmup 60
 run c2_batch32 --batch 32 --steps 400 --warmup 100
 run c2_batch32_shadow --batch 32 --shadow 1 --steps 400 --warmup 100
 run c2_batch8_shadow --batch 8 --shadow 1 --steps 400 --warmup 100
