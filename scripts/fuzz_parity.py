@@ -96,10 +96,11 @@ def one_search_case(i):
         cuts = sorted(set([0, n] + rs.randint(1, n, size=s - 1).tolist()))
         cc = min(2 * k, n)
         qd = torch.from_numpy(Q).cuda()
-        lists = []
+        lists, families = [], set()
         for lo, hi in zip(cuts[:-1], cuts[1:]):
             sh = eng.DeviceCorpus(c.emb[lo:hi], c.dewi32[lo:hi], c.ent32[lo:hi], space, id_offset=lo)   # (no shadow: shard records)
             lists.append(sh.candidates_device(qd, cc))
+            families.add(sh.scan_kernel_name(b, k, candidates=cc).split("<")[0].startswith("mfma"))
         case["cuts"] = cuts
         LAST.update(family="shards", cuts=cuts)
         m_ids, m_sc = eng.merge_rerank_device(torch.stack(lists), cc, k, eta, pref)
@@ -110,8 +111,10 @@ def one_search_case(i):
         both = (ok & m_ok).cpu().numpy()
         # per-row sums do not depend on the shard a row is in when the same kernel family serves both; a shard too
         # small for the matrix-core pass takes the row kernels (other summation order): compare through the oracle then
-        same_path = (all((hi - lo) >= 64 * 1024 for lo, hi in zip(cuts[:-1], cuts[1:])) or b < (2 if bf16 else 5) or n < 64 * 1024) \
-            and c.shadow is None
+        # (which family serves a shape is the library's own answer, dewi_knn_scan_kernel: since round 4 the batch size from which
+        # the matrix-core pass is taken depends on the element type, the space and the width)
+        families.add(c.scan_kernel_name(b, k).split("<")[0].startswith("mfma"))
+        same_path = len(families) == 1 and c.shadow is None
         # the bf16 row kernel takes 1536-byte rows in pairs: a row's sum depends on its place in the pair, so only
         # shards that start on even rows (what dewi.sharded.shard_bounds produces) are bit-equal to the whole there
         pairs_kept = not (bf16 and dim == 768) or all(lo % 2 == 0 for lo in cuts[:-1])
