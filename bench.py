@@ -277,7 +277,7 @@ def run_c2(args, torch, dist, eng, nat, rank, world, device):
     n_q = args.warmup + args.steps
     B = args.batch
     # (the headline line — no flags, one query per step — never takes the shadow: it stays the plain fp32 scan over N*d*4 bytes)
-    shadowed = (B > 32 if args.shadow < 0 else args.shadow == 1) and world == 1 and args.dim in (256, 512, 768, 1024, 1536) and \
+    shadowed = (B > 32 if args.shadow < 0 else args.shadow == 1) and world == 1 and args.dim % 32 == 0 and 160 <= args.dim <= 1536 and \
         min(2 * args.k, total_rows) <= (512 if B > 32 else 256)
     if shadowed:
         # query batches over the fp32 corpus: a matrix-core pass over a bf16 shadow copy as a pre-selection, candidates
@@ -446,8 +446,8 @@ def run_c2(args, torch, dist, eng, nat, rank, world, device):
     depth_args = f"{-(-args.dim // 256)},false,false,{'true' if args.dim % 256 else 'false'}"   # chunks, SAMPLE, L2, partial last chunk
     lib_name = corpus.scan_kernel_name(B, k)       # what the library's plan says streams the corpus for this shape
     kernel = ((f"mfma_scan_f32<false,{depth_args}>" if lib_name.startswith("mfma_scan_f32") else lib_name) if not shadowed
-              else f"mfma_scan_bf16_s16<{args.dim // 16},false>" if B > 32
-              else f"scan_rows_bf16<{args.dim // 256},1,0,1,true>" if (B == 1 and c <= 32 and args.dim <= 1024)   # (no bf16 row kernel at 1536)
+              else f"mfma_scan_bf16_s16<{args.dim // 16},false>" if (B > 32 and args.dim % 128 == 0 and args.dim <= 768)
+              else f"scan_rows_bf16<{args.dim // 256},1,0,1,true>" if (B == 1 and c <= 32 and args.dim <= 1024 and args.dim % 256 == 0)   # (no tuned bf16 row kernel at 1536 / other widths)
               else f"mfma_scan_f32<true,{depth_args}>")
     traffic, traffic_note = recorded_traffic(f"{n_local}x{args.dim}x{elem}xB{B}", kernel)
     if traffic is None and shadowed and B < 32 and kernel.startswith("mfma_scan_f32"):

@@ -161,8 +161,8 @@ __device__ __forceinline__ void split3(const u32x4f& x0, const u32x4f& x1, u32x4
 //     in the last chunk the waves w >= vw have nothing of this row — they still move their DMA pieces (a piece of the partial
 //     chunk carries the head of the NEXT row behind the row's tail; past the tile's last row the buffer descriptor returns
 //     zeros) and keep every barrier, but skip their matrix instructions: a NaN in the neighbouring row must not reach this
-//     row's score through a 0 x NaN product.  Row stride and query stride become run-time values.  Cosine only (an l2 batch at
-//     such a width would need the exact re-scoring at that width: it takes the row kernels).
+//     row's score through a 0 x NaN product.  Row stride and query stride become run-time values.  Cosine, and l2 over an fp32
+//     corpus (exact-refine mode: the select re-scores with scan_rows_any's arithmetic, widths from 160 columns).
 template <bool BF16, int CH, bool SAMPLE, bool L2, bool PARTIAL = false>
 __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __restrict__ E, int64_t n_rows,
                                                                 const void* __restrict__ Qn, int64_t n_tiles,
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
 #if defined(__HIP_DEVICE_COMPILE__)
   const float l2_margin = L2 ? aux : 0.f;
   using G = DepthGeo<BF16>;
-  static_assert(!(PARTIAL && L2), "partial last chunk: cosine only");
+  static_assert(!(PARTIAL && L2 && BF16), "partial last chunk + l2: fp32 corpora (exact-refine mode) only");
   const int DIM = PARTIAL ? (CH - 1) * kF32ChunkCols + 32 * vw : CH * kF32ChunkCols;   // compile-time unless PARTIAL
   constexpr int RM = G::kRing - 1;                             // ring slot of chunk g: g & RM
   extern __shared__ __attribute__((aligned(16))) char lds[];   // ring | partial sums | per-query counters
@@ -561,7 +561,10 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
       const f32x16f zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const bool skip = PARTIAL && ch == CH - 1 && w >= vw;   // wave-uniform (PARTIAL: see the kernel's header)
       if (skip) {
-        if (ch == 0) acc = zero;                              // a one-chunk row: this wave contributes nothing at all
+        if (ch == 0) {                                        // a one-chunk row: this wave contributes nothing at all
+          acc = zero;
+          nrm_a = nrm_b = 0.f;
+        }
 #pragma unroll
         for (int p = 0; p < G::kPieces; ++p) issue_piece(rs4, (ch + G::kRing) % CH, static_cast<int>((g + G::kRing) & RM), p);
       } else if constexpr (kSplit) {
@@ -673,8 +676,11 @@ bool mfma_f32_path_supported(int elem_type, int64_t n_rows, int dim, int n_queri
   if ((space != DEWI_SPACE_COSINE && space != DEWI_SPACE_L2) || n_queries < min_q || n_rows < 64 * 1024 || n_candidates > 256 || dim <= 0)
     return false;
   if (dim % kF32ChunkCols != 0) {
-    // a partial last chunk (round 4): any dim % 32 == 0 up to 1536 columns, cosine
-    return space == DEWI_SPACE_COSINE && dim % 32 == 0 && dim < 6 * kF32ChunkCols;
+    // a partial last chunk (round 4): any dim % 32 == 0 up to 1536 columns, cosine; l2 over an fp32 corpus (exact-refine mode) from
+    // 160 columns (below, the one-query kernel is scan_short_rows_any, whose arithmetic the re-scoring does not repeat) to 768
+    if (dim % 32 != 0 || dim >= 6 * kF32ChunkCols) return false;
+    if (space == DEWI_SPACE_COSINE) return true;
+    return elem_type == 0 && dim >= 160 && dim < kF32MaxL2Chunks * kF32ChunkCols;
   }
   const int ch = dim / kF32ChunkCols;
   if (space == DEWI_SPACE_L2) {
@@ -726,8 +732,8 @@ static hipError_t run_mfma_f32_dim(const MfmaF32Layout& m, const void* E, int64_
                                    char* ws, hipStream_t stream, float thr_bias, int vw = 8) {
   // l2 over an fp32 corpus runs in exact-refine mode (see stage2_finish and select_rerank.hip): error bound per unit of
   // ||e||^2 + ||q||^2.  bf16 corpora (opt-in, approximate) and cosine: no margin.
-  const float l2_margin = L2 ? (BF16 ? 0.f : depth_l2_margin(CH * kF32ChunkCols)) : thr_bias;   // the kernel's `aux`
   const int DIM = PARTIAL ? (CH - 1) * kF32ChunkCols + 32 * vw : CH * kF32ChunkCols;
+  const float l2_margin = L2 ? (BF16 ? 0.f : depth_l2_margin(DIM)) : thr_bias;   // the kernel's `aux`
   constexpr int kLds = depth_lds_bytes<BF16>();
   static PerDeviceOnce attr_once;   // one per instantiation
   const hipError_t ea = attr_once.run([] {
@@ -790,9 +796,18 @@ hipError_t launch_mfma_f32(const MfmaF32Layout& m, int elem_type, const void* d_
     }                                                                                                                        \
     return elem_type ? run_mfma_f32_dim<true, CH, false>(m, d_E, n_rows, n_queries, n_candidates, ws, stream, thr_bias)      \
                      : run_mfma_f32_dim<false, CH, false>(m, d_E, n_rows, n_queries, n_candidates, ws, stream, thr_bias);
-  if (dim % kF32ChunkCols != 0) {      // a partial last chunk: cosine, up to four chunks (mfma_f32_path_supported)
-    if (l2 || dim % 32 != 0) return hipErrorInvalidValue;
+  if (dim % kF32ChunkCols != 0) {      // a partial last chunk (mfma_f32_path_supported)
+    if (dim % 32 != 0) return hipErrorInvalidValue;
     const int vw = (dim % kF32ChunkCols) / 32;
+    if (l2) {                          // fp32 corpus, exact-refine mode, up to three chunks
+      if (elem_type) return hipErrorInvalidValue;
+      switch (dim / kF32ChunkCols + 1) {
+        case 1: return run_mfma_f32_dim<false, 1, true, true>(m, d_E, n_rows, n_queries, n_candidates, ws, stream, 0.f, vw);
+        case 2: return run_mfma_f32_dim<false, 2, true, true>(m, d_E, n_rows, n_queries, n_candidates, ws, stream, 0.f, vw);
+        case 3: return run_mfma_f32_dim<false, 3, true, true>(m, d_E, n_rows, n_queries, n_candidates, ws, stream, 0.f, vw);
+        default: return hipErrorInvalidValue;
+      }
+    }
 #define DEWI_DEPTH_PARTIAL(CH)                                                                                                  \
   case CH:                                                                                                                      \
     return elem_type ? run_mfma_f32_dim<true, CH, false, true>(m, d_E, n_rows, n_queries, n_candidates, ws, stream, thr_bias, vw) \

@@ -221,7 +221,7 @@ struct RefineParams {
   const float* E;        // corpus rows [n_rows][dim] fp32 (NULL: off)
   const float* Q;        // this launch's RAW queries [n_queries][dim] fp32 (cosine: normalised here as the row kernels do)
   const float* qn2;      // l2: ||q||^2 per query
-  int dim;               // 256, 512 or 768
+  int dim;               // any dim % 4 == 0 from 132 to 1536 columns whose one-query search takes scan_rows_f32 / scan_rows_any
   float margin;          // l2: depth_l2_margin(dim), the bound per unit of ||e||^2 + ||q||^2; cosine: the bound itself
   int space;             // DEWI_SPACE_*
   int list_len;          // > 0: the keys are `sorted_lists` sorted lists of THIS length from a row kernel over the bf16 shadow

@@ -340,12 +340,21 @@ __device__ __forceinline__ int refine_rescore_units(uint64_t* keys, int n_candid
   // (the candidates of a query are a few dozen to a few hundred 3 KiB rows: latency, not bandwidth)
   // <4, 4>: l2 over an fp32 corpus on the matrix cores (dim 256 / 512 / 768) and the bf16 shadow up to dim 1024; <6, 2>: the shadow at
   // dim 1536 (six units per lane: two candidates per wave and round keep the row fragments inside the register budget)
-  const int units = rf.dim >> 8;                   // U = dim / 256 sixteen-byte units per lane
+  // lane l takes the 16-byte units l + 64 u of the row that lie inside it (round 4: any dim % 4 == 0 from 132 columns on — the lane
+  // layout of scan_rows_any; the whole-KiB widths are the case where every unit exists: scan_rows_f32<U = dim / 256>)
+  const int n4 = rf.dim >> 2;                      // 16-byte units per row
+  const int units = (n4 + 63) >> 6;                // units per lane, the last one possibly partial
+  bool have[kMaxUnits];
+#pragma unroll
+  for (int u = 0; u < kMaxUnits; ++u) have[u] = lane + 64 * u < n4;
   typedef float f32x4r __attribute__((ext_vector_type(4)));
   const f32x4r* qp = reinterpret_cast<const f32x4r*>(rf.Q + static_cast<int64_t>(q) * rf.dim) + lane;
   f32x4r qv[kMaxUnits];
 #pragma unroll
-  for (int u = 0; u < kMaxUnits; ++u) qv[u] = u < units ? qp[u * 64] : f32x4r{0.f, 0.f, 0.f, 0.f};
+  for (int u = 0; u < kMaxUnits; ++u) {
+    qv[u] = f32x4r{0.f, 0.f, 0.f, 0.f};
+    if (u < units && have[u]) qv[u] = qp[u * 64];
+  }
   if (!l2) {   // cosine: the prepared query of scan_rows_f32 — float64 sum of squares in its order, one norm, __fdiv_rn
     double ss = 0.0;
 #pragma unroll
@@ -371,7 +380,10 @@ __device__ __forceinline__ int refine_rescore_units(uint64_t* keys, int n_candid
       rows[bb] = key_row(sh.sel2[t]);
       const f32x4r* ev = reinterpret_cast<const f32x4r*>(rf.E + static_cast<int64_t>(rows[bb]) * rf.dim) + lane;
 #pragma unroll
-      for (int u = 0; u < kMaxUnits; ++u) e[bb][u] = u < units ? ev[u * 64] : f32x4r{0.f, 0.f, 0.f, 0.f};
+      for (int u = 0; u < kMaxUnits; ++u) {
+        e[bb][u] = f32x4r{0.f, 0.f, 0.f, 0.f};      // (a unit past the row's end: e = q = 0, fmaf(0, 0, acc) == acc — scan_rows_any's predicated lanes)
+        if (u < units && have[u]) e[bb][u] = ev[u * 64];
+      }
     }
 #pragma unroll
     for (int bb = 0; bb < kBatch; ++bb) {

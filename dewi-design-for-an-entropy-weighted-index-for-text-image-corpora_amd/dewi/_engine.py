@@ -104,7 +104,7 @@ class DeviceCorpus:
         """Keep a bf16 copy of this fp32 matrix next to it (+50 % memory).  Batches of 2 or more cosine queries then run the
         matrix-core passes over the copy as a PRE-SELECTION — half the bytes, and 256 queries per corpus pass instead of
         32 for larger batches — and re-score the candidates from the fp32 rows with the row kernels' arithmetic
-        (``dewi_knn_rerank_f32_shadow``): results equal the one-query search bit for bit.  dim 256 / 512 / 768 / 1024 / 1536, >= 64 K
+        (``dewi_knn_rerank_f32_shadow``): results equal the one-query search bit for bit.  Every dim % 32 == 0 from 160 to 1536 columns, >= 64 K
         rows; any other shape simply takes the usual path.
 
         ``single_query=True`` sends one-query searches through the shadow as well (k <= 16: the bf16 row kernel with

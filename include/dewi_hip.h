@@ -141,7 +141,7 @@ int dewi_knn_rerank_f32(const float* d_E, int64_t n_rows, int dim, const float* 
  * proven bound of the fp32 ones (bf16 rounding of unit vectors: 2^-8 plus accumulation), the candidate cut is widened by
  * that bound — and the candidates are re-scored from the fp32 rows with the row kernels' arithmetic, so ids and scores
  * equal dewi_knn_rerank_f32's one-query results bit for bit.  The bound assumes STORED rows of norm <= 1.0001 (what
- * dewi_normalize_rows_f32 leaves; the host layer checks it once).  Cosine, dim 256 / 512 / 768 / 1024 / 1536, corpus >= 64 K rows;
+ * dewi_normalize_rows_f32 leaves; the host layer checks it once).  Cosine, every dim % 32 == 0 from 160 to 1536 columns (ABI 5; ABI 4: 256 / 512 / 768 / 1024 / 1536), corpus >= 64 K rows;
  * any other call (and d_E_bf16 == NULL) behaves exactly as dewi_knn_rerank_f32.  A query with more candidates inside
  * the error band than the sort holds is answered by the repair launches on the plain fp32 scan (ABI 5; ABI 4 returned
  * it refused, id -1).  (ABI 4.) */

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 BYTES=3072000000
 for d in $DIMS; do
   rows=$(( BYTES / (4 * d) ))
-  python3 bench.py --dim $d --docs $rows --steps 300 --warmup 30 --cpu-queries 0 --latency-queries 0 > $OUT/bench_dim$d.json 2> $OUT/bench_dim$d.err || { tail -5 $OUT/bench_dim$d.err; exit 1; }
+  python3 bench.py --dim $d --docs $rows --steps 300 --warmup 30 --cpu-queries 64 --latency-queries 0 > $OUT/bench_dim$d.json 2> $OUT/bench_dim$d.err || { tail -5 $OUT/bench_dim$d.err; exit 1; }
   python3 - "$OUT/bench_dim$d.json" <<'PY'
 import json, sys
 r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

@@ -14,16 +14,22 @@ run c2
 run c2_steps20 --steps 20 --warmup 5
 run c2_steps20_condition0 --steps 20 --warmup 5 --condition-ms 0
 # other embedding widths at equal corpus bytes (~3 GB, one query per step): the any-width row kernels
+# (--cpu-queries 64: the parity gate — 64 queries against the oracle — runs in these lines too; the CPU figure they carry is a
+# 64-query sample of THAT workload, not the headline's baseline)
 for d in 128 384 1000 1280 3072; do
-  run dim$d --dim $d --docs $(( 3072000000 / (4 * d) )) --cpu-queries 0
+  run dim$d --dim $d --docs $(( 3072000000 / (4 * d) )) --cpu-queries 64
 done
-run dim384_batch4 --dim 384 --docs 2000000 --batch 4 --cpu-queries 0
+run dim384_batch4 --dim 384 --docs 2000000 --batch 4 --cpu-queries 64
 # 32 queries per step at widths with a partial last chunk on the depth-split pass (round 4)
-run dim384_batch32 --dim 384 --docs 2000000 --batch 32 --steps 300 --warmup 60 --cpu-queries 0
-run dim640_batch32 --dim 640 --docs 1200000 --batch 32 --steps 300 --warmup 60 --cpu-queries 0
-run dim128_batch32 --dim 128 --docs 6000000 --batch 32 --steps 300 --warmup 60 --cpu-queries 0
-run dim1280_batch32 --dim 1280 --docs 600000 --batch 32 --steps 300 --warmup 60 --cpu-queries 0
-run dim2048_batch32 --dim 2048 --docs 375000 --batch 32 --steps 300 --warmup 60 --cpu-queries 0
+run dim384_batch32 --dim 384 --docs 2000000 --batch 32 --steps 300 --warmup 60 --cpu-queries 64
+run dim640_batch32 --dim 640 --docs 1200000 --batch 32 --steps 300 --warmup 60 --cpu-queries 64
+run dim128_batch32 --dim 128 --docs 6000000 --batch 32 --steps 300 --warmup 60 --cpu-queries 64
+run dim1280_batch32 --dim 1280 --docs 600000 --batch 32 --steps 300 --warmup 60 --cpu-queries 64
+run dim2048_batch32 --dim 2048 --docs 375000 --batch 32 --steps 300 --warmup 60 --cpu-queries 64
+# fp32 corpus + bf16 shadow at widths outside the dim = 256 U set (round 4)
+run dim384_batch256_shadow --dim 384 --docs 2000000 --batch 256 --steps 200 --warmup 40 --cpu-queries 64
+run dim384_batch32_shadow --dim 384 --docs 2000000 --batch 32 --shadow 1 --steps 200 --warmup 40 --cpu-queries 64
+run dim1280_batch32_shadow --dim 1280 --docs 600000 --batch 32 --shadow 1 --steps 200 --warmup 40 --cpu-queries 64
 run c3 --config c3
 run c4 --config c4
 run c5 --config c5

@@ -78,7 +78,7 @@ def one_search_case(i):
         kw = dict(gap=1e-6, score_tol=1e-5, prepared=True)
     else:
         E, Qo = c.emb.cpu().numpy(), Q
-        if space == "cosine" and dim in (256, 512, 768, 1024, 1536) and rs.rand() < 0.7:
+        if space == "cosine" and dim % 32 == 0 and 160 <= dim <= 1536 and rs.rand() < 0.7:
             c.enable_bf16_shadow(single_query=True)   # matrix-core pass over the bf16 shadow + exact re-scoring (1+ queries)
             LAST.update(shadow=True)
             done["shadow"] = done.get("shadow", 0) + 1
