@@ -43,6 +43,7 @@ class DeviceCorpus:
         self.device = emb.device
         self._lib = nat.load_library()
         self._ws: Dict[Tuple[int, int], "torch.Tensor"] = {}
+        self._ws_need: Dict[Tuple[int, int, int], Tuple[int, int]] = {}     # (batch, cut, thread) -> (tuning epoch, bytes)
         self._q_pinned = None
         self._q_dev = None
         self.shadow = None            # bf16 copy of an fp32 matrix (enable_bf16_shadow): pre-selection over half the bytes
@@ -149,11 +150,20 @@ class DeviceCorpus:
 
     # ------------------------------------------------------------------ helpers
     def _workspace(self, n_queries: int, n_candidates: int):
-        # the required size depends on the launch plan (tunable), so it is re-asked every call
-        need = int(self._lib.dewi_knn_workspace_bytes(self.n_rows, self.dim, n_queries, n_candidates))
-        if need == 0:
-            raise nat.NativeLibraryError("dewi_knn_workspace_bytes returned 0: " + nat.last_error())
+        # the required size depends on the launch plan (tunable): asked again whenever `tuning()` has been called since
+        # (the library call plans every path of the shape — a few microseconds that a 40 us search need not pay each time)
         key = (n_queries, n_candidates)
+        nkey = (n_queries, n_candidates, threading.get_ident())      # (the library's tuning is thread-local)
+        cached = self._ws_need.get(nkey)
+        if cached is not None and cached[0] == _tuning_epoch:
+            need = cached[1]
+        else:
+            need = int(self._lib.dewi_knn_workspace_bytes(self.n_rows, self.dim, n_queries, n_candidates))
+            if need == 0:
+                raise nat.NativeLibraryError("dewi_knn_workspace_bytes returned 0: " + nat.last_error())
+            if len(self._ws_need) > 64:
+                self._ws_need.clear()
+            self._ws_need[nkey] = (_tuning_epoch, need)
         ws = self._ws.get(key)
         if ws is None or ws.numel() < need:
             if len(self._ws) > 8:
@@ -176,8 +186,9 @@ class DeviceCorpus:
         q = np.ascontiguousarray(q)
         if self._q_pinned is None or self._q_pinned.shape != q.shape:
             self._q_pinned = torch.empty(q.shape, dtype=torch.float32, pin_memory=True)
+            self._q_pinned_np = self._q_pinned.numpy()
             self._q_dev = torch.empty(q.shape, dtype=torch.float32, device=self.device)
-        self._q_pinned.numpy()[...] = q
+        self._q_pinned_np[...] = q
         self._q_dev.copy_(self._q_pinned, non_blocking=True)
         return self._q_dev
 
@@ -462,11 +473,16 @@ def prepare_queries_bf16(q_dev, space: str = "cosine"):
     return out
 
 
+_tuning_epoch = 0      # bumped by tuning(): cached workspace sizes of every DeviceCorpus are asked for again
+
+
 def tuning(scan_blocks: int = 0, rows_per_iter: int = 0, nontemporal: int = -1, batched_mfma: int = 1) -> None:
     """Launch-shape overrides of the CALLING THREAD (the library keeps them thread-local).
     batched_mfma: 0 row kernels only; 1 (default) cosine batches on the matrix cores, ``space="l2"`` batches over an fp32
     corpus too (exact-refine mode: error-widened cut, candidates re-scored with the row kernels' arithmetic); 2 also l2
     batches over a bf16 corpus, unrefined (2<e,q> - ||e||^2 - ||q||^2: absolute error ~ulp(||e||^2+||q||^2) —
     near-duplicates of a query lose their near-zero distance; not the parity path)."""
+    global _tuning_epoch
+    _tuning_epoch += 1
     nat.check(nat.load_library().dewi_tuning_set(int(scan_blocks), int(rows_per_iter), int(nontemporal),
                                                  int(batched_mfma)))

@@ -447,7 +447,8 @@ class ExactIndex(BaseIndex):
     def results_for(self, rows: np.ndarray, scores: np.ndarray) -> List[SearchResult]:
         """Row indices/scores of ``search_batch`` -> the reference's (doc_id, score, Payload) tuples."""
         ids, at_row = self._doc_ids, self._payloads.at_row
-        self._payloads.ensure_rows(np.unique(np.asarray(rows)).tolist(), ids)      # device-resident payload columns: one gather
+        if self._payloads._blocks:      # column blocks (possibly device-resident): one gather for the rows that are wanted
+            self._payloads.ensure_rows(np.unique(np.asarray(rows)).tolist(), ids)
         return [[(ids[r], float(s), at_row(r, ids[r])) for r, s in zip(rr.tolist(), ss.tolist())]
                 for rr, ss in zip(rows, scores)]
 
