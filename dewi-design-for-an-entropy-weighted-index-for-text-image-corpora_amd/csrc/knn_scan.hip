@@ -151,9 +151,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_rows_f32_flagged(const floa
 }
 
 // ---------------------------------------------------------------------------------------------
-// Generic path: any dim.  G (power of two <= 64) lanes share a row, a wave covers 64/G rows per
-// step; queries come pre-normalised from global memory (L1/L2 resident).  VEC = 4 when rows can
-// be read as float4 (dim % 4 == 0, 16-byte aligned base), else scalar loads.
+// Generic path: any dim (since round 4 only rows wider than 1024 units reach it: scan_any.hpp serves the rest).  G (power
+// of two <= 64) lanes share a row, a wave covers 64/G rows per step; queries come pre-normalised from global memory
+// (L1/L2 resident).  VEC = 4 when rows can be read as float4 (dim % 4 == 0, 16-byte aligned base), else scalar loads.
 // ---------------------------------------------------------------------------------------------
 template <int VEC>
 struct VecT;
@@ -399,6 +399,38 @@ ScanPlan plan_scan(int64_t n_rows, int dim, int elem_bytes, int n_candidates, in
       p.rows_per_iter_batch = any_rows(p.u_pad, p.nq_max, p.level);
     }
   }
+  // rows that are NOT whole units (round 4; they used to take scan_generic_*): the same two kernels in their PH form —
+  // aligned 16-byte loads, each wave / lane group on the rows of one residue mod G = 16 / gcd(16, row bytes)
+  p.odd_rows = false;
+  p.row_cols = dim;
+  if (!p.fast && dim % cols_per_unit != 0) {
+    const int row_bytes = dim * elem_bytes;
+    const int most_units = (row_bytes + (16 - elem_bytes) + 15) / 16;   // a row that starts 16 - elem_bytes into its first unit
+    int period = 16, tz = 0;
+    while (tz < 4 && (row_bytes >> tz) % 2 == 0) ++tz;
+    period >>= tz;
+    int log2p = 0;
+    while ((1 << log2p) < most_units) ++log2p;
+    if (most_units <= 32 && (kWave >> log2p) % period == 0) {
+      p.kind = kScanAnyShort;
+      p.odd_rows = true;
+      p.units = most_units;
+      p.log2p = log2p;
+      p.rows_per_iter = p.rows_per_iter_batch = (kWave >> p.log2p) * kAnyShortRows;
+    } else if (most_units <= 64 * 16) {
+      static const int pads[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
+      const int need = (most_units + 63) / 64;
+      p.kind = kScanAnyLong;
+      p.odd_rows = true;
+      p.units = most_units;
+      for (int v : pads)
+        if (v >= need) { p.u_pad = v; break; }
+      p.nq_max = any_nq_max_odd(p.u_pad);
+      p.level = tuning.rows_per_iter > 0 ? (tuning.rows_per_iter - 1) % kAnyLevels : any_level(most_units);
+      p.rows_per_iter = any_rows(p.u_pad, 1, p.level);
+      p.rows_per_iter_batch = any_rows(p.u_pad, p.nq_max, p.level);
+    }
+  }
   p.raw_queries = p.kind != kScanGeneric;
   p.nontemporal = tuning.nontemporal < 0 ? true : tuning.nontemporal != 0;
   // One 8-wave workgroup per CU (8 waves x R*U KiB in flight each): 8 waves per CU measured
@@ -521,7 +553,8 @@ bool scan_flagged_supported(const ScanPlan& plan, int elem_bytes) {
   if (plan.kind == kScanFast) return true;
   // any-width kernels: the widths the matrix-core passes run at outside the dim = 256 U set — dim % 32 == 0 up to 1536
   // columns (the depth-split pass with a partial last chunk), 1280 / 2048, bf16 also 3072 / 4096 (512 units per row)
-  return plan.kind == kScanAnyShort || (plan.kind == kScanAnyLong && plan.u_pad <= 8);
+  // (rows that are not whole units never meet a matrix-core pass: those need dim % 32 == 0)
+  return !plan.odd_rows && (plan.kind == kScanAnyShort || (plan.kind == kScanAnyLong && plan.u_pad <= 8));
 }
 
 hipError_t launch_scan_flagged_f32(const ScanPlan& plan, const float* d_E, int64_t n_rows, int dim, const float* d_q_raw,
@@ -550,6 +583,7 @@ hipError_t launch_scan_flagged_f32(const ScanPlan& plan, const float* d_E, int64
 hipError_t launch_scan_f32(const ScanPlan& plan, const float* d_E, int64_t n_rows, int dim, const float* d_q_raw,
                            const float* d_q_norm, int q0, int nq, int n_candidates, int space, uint64_t* d_keys,
                            hipStream_t stream) {
+  if (plan.odd_rows) return launch_scan_odd_f32(plan, d_E, n_rows, dim, d_q_raw, q0, nq, n_candidates, space, d_keys, stream);
   if (plan.kind == kScanAnyLong || plan.kind == kScanAnyShort)
     return launch_scan_any_f32(plan, d_E, n_rows, dim, d_q_raw, q0, nq, n_candidates, space, d_keys, stream);
   const float* qr = d_q_raw + static_cast<int64_t>(q0) * dim;

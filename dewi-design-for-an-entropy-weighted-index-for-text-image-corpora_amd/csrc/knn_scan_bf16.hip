@@ -363,6 +363,7 @@ hipError_t launch_scan_flagged_bf16(const ScanPlan& plan, const uint16_t* d_E, i
 hipError_t launch_scan_bf16(const ScanPlan& plan, const uint16_t* d_E, int64_t n_rows, int dim, const float* d_q_raw,
                             const float* d_q_norm, int q0, int nq, int n_candidates, int space, uint64_t* d_keys,
                             hipStream_t stream) {
+  if (plan.odd_rows) return launch_scan_odd_bf16(plan, d_E, n_rows, dim, d_q_raw, q0, nq, n_candidates, space, d_keys, stream);
   if (plan.kind == kScanAnyLong || plan.kind == kScanAnyShort)
     return launch_scan_any_bf16(plan, d_E, n_rows, dim, d_q_raw, q0, nq, n_candidates, space, d_keys, stream);
   const float* qr = d_q_raw + static_cast<int64_t>(q0) * dim;

@@ -44,7 +44,8 @@ constexpr int kScanThreads = DEWI_SCAN_THREADS;   // 8 waves per workgroup (256 
 constexpr int kSelectThreads = 1024;
 
 // which row kernel serves a (dim, element type): the tuned dim = 256 U kernels, the any-width kernels of scan_any.hpp
-// (rows of whole 16-byte units), or the scalar-capable generic kernel (anything else)
+// (rows of whole 16-byte units, and — ScanPlan::odd_rows — rows that are not), or the scalar-capable generic kernel (rows
+// wider than 1024 units)
 enum ScanKind { kScanFast = 0, kScanAnyLong = 1, kScanAnyShort = 2, kScanGeneric = 3 };
 
 struct ScanPlan {
@@ -65,6 +66,8 @@ struct ScanPlan {
   int u_pad;          // kScanAnyLong: units per lane the instantiated kernel holds (>= ceil(units / 64))
   int log2p;          // kScanAnyShort: log2 of the lanes that share a row
   int level;          // kScanAnyLong: which rows-in-flight choice of its units-per-lane count (scan_any.hpp any_level / any_rows)
+  bool odd_rows;      // any-width kernels: rows are NOT whole 16-byte units (fp32: dim % 4, bf16: dim % 8) — the PH = true kernels
+  int row_cols;       // odd_rows: columns per row (what those kernels take instead of `units`; `units` is then the most a row touches)
   int nq_max;         // most queries one corpus pass of the row kernel serves besides 1 (4; 2 or 1 for wide rows: scan_any.hpp any_nq_max)
   bool raw_queries;   // the kernel normalises the raw queries itself (everything but kScanGeneric)
   int64_t keys_per_query;  // number of uint64 keys the scan emits per query
@@ -105,6 +108,12 @@ hipError_t launch_scan_f32(const ScanPlan& plan, const float* d_E, int64_t n_row
 hipError_t launch_scan_any_f32(const ScanPlan& plan, const float* d_E, int64_t n_rows, int dim, const float* d_q_raw, int q0,
                                int nq, int n_candidates, int space, uint64_t* d_keys, hipStream_t stream);
 hipError_t launch_scan_any_bf16(const ScanPlan& plan, const uint16_t* d_E, int64_t n_rows, int dim, const float* d_q_raw, int q0,
+                                int nq, int n_candidates, int space, uint64_t* d_keys, hipStream_t stream);
+
+// ---- knn_scan_odd_f32.hip / knn_scan_odd_bf16.hip: the same kernels for rows that are not whole units (plan.odd_rows)
+hipError_t launch_scan_odd_f32(const ScanPlan& plan, const float* d_E, int64_t n_rows, int dim, const float* d_q_raw, int q0,
+                               int nq, int n_candidates, int space, uint64_t* d_keys, hipStream_t stream);
+hipError_t launch_scan_odd_bf16(const ScanPlan& plan, const uint16_t* d_E, int64_t n_rows, int dim, const float* d_q_raw, int q0,
                                 int nq, int n_candidates, int space, uint64_t* d_keys, hipStream_t stream);
 
 // REPAIR launches (abi.cpp batch_repair): ONE launch scans the corpus once for every query q of [0, n_queries) whose

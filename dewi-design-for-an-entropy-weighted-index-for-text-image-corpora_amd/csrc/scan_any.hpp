@@ -1,4 +1,4 @@
-// Row scan for ANY embedding width whose rows are whole 16-byte units (fp32: dim % 4 == 0, bf16: dim % 8 == 0), gfx950.
+// Row scan for ANY embedding width up to 1024 16-byte units per row (fp32: 4096 columns, bf16: 8192), gfx950.
 //
 // Same contract as knn_scan.hip (steps 1-3 of ExactIndex.search, reference src/dewi/backends.py:420-444 — one BLAS call
 // for every dim there, `np.dot(self._embeddings, query)` :431-433): normalise the query, score every row, keep the best c
@@ -14,6 +14,10 @@
 //                        rows (one contiguous span), R such loads are in flight; the P partial sums are folded on the DPP
 //                        crossbar (quad_perm, row_half_mirror, row_mirror, row_bcast15) and the lane that ends up with a row's
 //                        score offers it to the wave's list — a ballot finds the few rows worth an offer.
+//
+// Each in two forms: rows that are whole units (fp32: dim % 4 == 0, bf16: dim % 8 == 0; PH = false) and rows that are not
+// (PH = true, see unit_keep_mask below) — so every width up to 1024 units streams the corpus with aligned 16-byte loads and
+// register-resident queries; scan_generic_* is left with rows wider than that.
 //
 // Roofline: HBM.  Algorithmic bytes per launch = n_rows * dim * sizeof(elem) + n_queries * dim * 4.
 #pragma once
@@ -33,6 +37,16 @@ struct UnitFrag<0, SPACE> {   // fp32 rows: 4 columns per unit
   __device__ __forceinline__ void load(const float* __restrict__ qrow, int unit, bool active) {
     q = f32x4{0.f, 0.f, 0.f, 0.f};
     if (active) q = reinterpret_cast<const f32x4*>(qrow)[unit];
+  }
+  // rows that are not whole units: the unit's first column is `first` (negative before the row, >= dim behind it: zeros there)
+  __device__ __forceinline__ void load_shifted(const float* __restrict__ qrow, int first, int dim) {
+    float t[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = first + e;
+      t[e] = static_cast<unsigned>(idx) < static_cast<unsigned>(dim) ? qrow[idx] : 0.f;
+    }
+    q = f32x4{t[0], t[1], t[2], t[3]};
   }
   __device__ __forceinline__ double sumsq() const { return square_f64(q.x) + square_f64(q.y) + square_f64(q.z) + square_f64(q.w); }
   __device__ __forceinline__ void scale(float norm) {
@@ -58,6 +72,13 @@ struct UnitFrag<1, SPACE> {   // bf16 rows: 8 columns per unit; the prepared que
     f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w;
     f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
   }
+  __device__ __forceinline__ void load_shifted(const float* __restrict__ qrow, int first, int dim) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int idx = first + e;
+      f[e] = static_cast<unsigned>(idx) < static_cast<unsigned>(dim) ? qrow[idx] : 0.f;
+    }
+  }
   __device__ __forceinline__ double sumsq() const {
     double s = 0.0;
 #pragma unroll
@@ -81,6 +102,35 @@ struct UnitFrag<1, SPACE> {   // bf16 rows: 8 columns per unit; the prepared que
     else return dot8<SPACE>(e, f, acc);
   }
 };
+
+// Rows that are NOT whole 16-byte units (fp32: dim % 4 != 0, bf16: dim % 8 != 0; or a shard whose first row does not start on a
+// unit) — the PH = true forms of both kernels.  The loads stay aligned 16-byte units; a row then starts `head` bytes into its first unit
+// and that offset repeats every G = 16 / gcd(16, row bytes) rows.  A wave (long rows) or a lane group (short rows) only ever takes rows
+// of ONE residue mod G, so its query fragments are loaded once, shifted by its own head, zero outside the row; the first and the last
+// unit of a row also hold columns of the neighbouring rows (read again by the wave that owns them: <= 2 units per row of extra traffic)
+// and those are cleared with a bit mask before the arithmetic — a NaN / Inf neighbour must not reach this row's sum.
+// The bits to keep of the unit whose first column is `first`:
+template <int ELEM>
+__device__ __forceinline__ u32x4 unit_keep_mask(int first, int dim) {
+  uint32_t m[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    if constexpr (ELEM == 0) {
+      m[d] = static_cast<unsigned>(first + d) < static_cast<unsigned>(dim) ? 0xFFFFFFFFu : 0u;
+    } else {
+      m[d] = (static_cast<unsigned>(first + 2 * d) < static_cast<unsigned>(dim) ? 0x0000FFFFu : 0u) |
+             (static_cast<unsigned>(first + 2 * d + 1) < static_cast<unsigned>(dim) ? 0xFFFF0000u : 0u);
+    }
+  }
+  return u32x4{m[0], m[1], m[2], m[3]};
+}
+__device__ __forceinline__ u32x4 and_u4(u32x4 a, u32x4 b) { return u32x4{a.x & b.x, a.y & b.y, a.z & b.z, a.w & b.w}; }
+// the raw query's float64 sum of squares, lane-strided: the same per-lane partial sums whatever the wave's head is
+__device__ __forceinline__ double strided_sumsq(const float* __restrict__ qrow, int dim, int lane) {
+  double ss = 0.0;
+  for (int i = lane; i < dim; i += kWave) ss += square_f64(qrow[i]);
+  return ss;
+}
 
 // Rows a wave issues before its first reduction.  Measured on MI355X at 3 GB (scripts/sweep_any.sh, profiles/r04): rows
 // that are not whole KiB want ~5-6 KiB in flight per wave — more than the 3 KiB of the dim = 768 kernel, because the
@@ -114,6 +164,7 @@ constexpr int any_rows(int u, int nq, int level) {
   if (u == 4) return level == 0 ? 2 : 1;
   return 1;
 }
+constexpr int any_nq_max_odd(int u_pad) { return u_pad <= 4 ? 4 : 1; }   // rows that are not whole units (PH kernels)
 // most queries one corpus pass serves besides 1 (launch_any_long instantiates exactly these)
 constexpr int any_nq_max(int elem_bytes, int u_pad) {
   if (elem_bytes == 2) return u_pad <= 4 ? 4 : (u_pad <= 8 ? 2 : 1);
@@ -124,21 +175,48 @@ constexpr int kAnyShortRows = DEWI_ANY_RSHORT;   // loads (of 64 / P rows each) 
 // ---------------------------------------------------------------------------------------------
 // 33 .. 64 U units per row
 // ---------------------------------------------------------------------------------------------
-template <int ELEM, int U, int R, int NQ, int SPACE, int S>
+// `units`: 16-byte units per row; PH (rows that are not whole units): COLUMNS per row instead.
+template <int ELEM, int U, int R, int NQ, int SPACE, int S, bool PH = false>
 __device__ __forceinline__ void scan_rows_any_body(const u32x4* __restrict__ E, int64_t n_rows, int units,
                                                    const float* __restrict__ Q, int n_candidates,
                                                    uint64_t* __restrict__ keys, int64_t keys_per_query, MergeShared& merge_buf) {
   constexpr int kCols = ELEM ? 8 : 4;
+  constexpr int kElemBytes = ELEM ? 2 : 4;
   constexpr bool DENSE = S == 0;
   const int lane = lane_id();
-  const int wave_in_block = static_cast<int>(threadIdx.x) >> 6;
+  // (wave-uniform on purpose: row numbers and row addresses then live in scalar registers — without it the compiler keeps one
+  // 64-bit vector address per row in flight and updates each of them every iteration)
+  const int wave_in_block = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
   const int64_t gwave = static_cast<int64_t>(blockIdx.x) * (kScanThreads / kWave) + wave_in_block;
   const int64_t n_waves = static_cast<int64_t>(gridDim.x) * (kScanThreads / kWave);
-  const int dim = units * kCols;
+  const int dim = PH ? units : units * kCols;
+  // PH: this wave takes the rows ph, ph + G, ph + 2 G, ... — all of them start head_el columns into their first unit
+  int row_step = 1, ph = 0, off0 = 0, head_el = 0, row_bytes = 0;
+  int64_t wave_pos = gwave, wave_cnt = n_waves;      // this wave's place among the waves that share its rows
+  if constexpr (PH) {
+    off0 = static_cast<int>(reinterpret_cast<uintptr_t>(E) & 15u);
+    E = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(E) - off0);   // (pointer arithmetic: stays a global pointer)
+    row_bytes = dim * kElemBytes;
+    const int tz = __builtin_ctz(static_cast<unsigned>(row_bytes) | 16u);   // row_step = 16 / gcd(16, row bytes)
+    row_step = 16 >> tz;
+    ph = static_cast<int>(gwave & (row_step - 1));
+    wave_pos = gwave >> (4 - tz);
+    wave_cnt = (n_waves - ph + row_step - 1) >> (4 - tz);                   // (n_waves >= 8 >= row_step: never 0)
+    const int head = (off0 + ph * row_bytes) & 15;
+    head_el = head / kElemBytes;
+    units = (head + row_bytes + 15) >> 4;                                   // units THIS wave's rows touch
+  }
 
   bool act[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) act[u] = lane + 64 * u < units;
+  [[maybe_unused]] u32x4 keep_first, keep_last;        // PH: the row's own columns in its first / last unit
+  [[maybe_unused]] int u_last = 0;
+  if constexpr (PH) {
+    u_last = (units - 1) >> 6;
+    keep_first = unit_keep_mask<ELEM>(lane * kCols - head_el, dim);
+    keep_last = unit_keep_mask<ELEM>((lane + 64 * u_last) * kCols - head_el, dim);
+  }
 
   // Query fragments, normalised here for cosine (reference backends.py:420-424) with the float64-summed norm every
   // kernel uses (common.hpp wave_query_norm): a query has one prepared form whatever kernel serves it.
@@ -149,9 +227,14 @@ __device__ __forceinline__ void scan_rows_any_body(const u32x4* __restrict__ E, 
     double ss = 0.0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      qf[qi][u].load(qrow, lane + 64 * u, act[u]);
-      ss += qf[qi][u].sumsq();
+      if constexpr (PH) {
+        qf[qi][u].load_shifted(qrow, (lane + 64 * u) * kCols - head_el, dim);
+      } else {
+        qf[qi][u].load(qrow, lane + 64 * u, act[u]);
+        ss += qf[qi][u].sumsq();
+      }
     }
+    if constexpr (PH && SPACE == DEWI_SPACE_COSINE) ss = strided_sumsq(qrow, dim, lane);
     if constexpr (SPACE == DEWI_SPACE_COSINE) {
       const float norm = wave_query_norm(ss);
       if (norm > 0.f) {
@@ -169,15 +252,24 @@ __device__ __forceinline__ void scan_rows_any_body(const u32x4* __restrict__ E, 
     for (int qi = 0; qi < NQ; ++qi) lst[qi].init(n_candidates, lane);
   }
 
-  auto fetch = [&](u32x4(&v)[U], int64_t row) {
-    const u32x4* p = E + row * units + lane;
+  // i: index among this wave's rows (not PH: the row itself).  Consecutive rows of a wave are a whole number of units apart.
+  const int64_t row_units = PH ? (static_cast<int64_t>(row_step) * row_bytes) >> 4 : units;
+  auto row_of = [&](int64_t i) { return PH ? ph + row_step * i : i; };
+  auto first_unit = [&](int64_t i) { return PH ? (off0 + row_of(i) * row_bytes) >> 4 : i * units; };
+  auto fetch = [&](u32x4(&v)[U], const u32x4* p) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       v[u] = u32x4{0u, 0u, 0u, 0u};
       if (act[u]) v[u] = load_u4<true>(p + 64 * u);
     }
   };
-  auto consume = [&](const u32x4(&v)[U], int64_t row) {
+  auto consume = [&](u32x4(&v)[U], int64_t row) {
+    if constexpr (PH) {
+      v[0] = and_u4(v[0], keep_first);
+#pragma unroll
+      for (int u = 1; u < U; ++u)
+        if (u == u_last) v[u] = and_u4(v[u], keep_last);
+    }
 #pragma unroll
     for (int qi = 0; qi < NQ; ++qi) {
       float acc = 0.f;
@@ -193,18 +285,21 @@ __device__ __forceinline__ void scan_rows_any_body(const u32x4* __restrict__ E, 
     }
   };
 
-  const int64_t n_groups = n_rows / R;
-  for (int64_t g = gwave; g < n_groups; g += n_waves) {
+  // rows of this wave's residue: ph + row_step * i, i in [0, n_mine)   (not PH: every row, i = the row)
+  const int64_t n_mine = PH ? (n_rows > ph ? (n_rows - ph + row_step - 1) / row_step : 0) : n_rows;
+  const int64_t n_groups = n_mine / R;
+  for (int64_t g = wave_pos; g < n_groups; g += wave_cnt) {
     u32x4 v[R][U];
+    const u32x4* p = E + first_unit(g * R) + lane;
 #pragma unroll
-    for (int r = 0; r < R; ++r) fetch(v[r], g * R + r);
+    for (int r = 0; r < R; ++r) fetch(v[r], p + r * row_units);
 #pragma unroll
-    for (int r = 0; r < R; ++r) consume(v[r], g * R + r);
+    for (int r = 0; r < R; ++r) consume(v[r], row_of(g * R + r));
   }
-  for (int64_t row = n_groups * R + gwave; row < n_rows; row += n_waves) {   // fewer than R rows left
+  for (int64_t i = n_groups * R + wave_pos; i < n_mine; i += wave_cnt) {   // fewer than R rows left
     u32x4 v[U];
-    fetch(v, row);
-    consume(v, row);
+    fetch(v, E + first_unit(i) + lane);
+    consume(v, row_of(i));
   }
 
   if constexpr (S == 1) {
@@ -219,12 +314,12 @@ __device__ __forceinline__ void scan_rows_any_body(const u32x4* __restrict__ E, 
   }
 }
 
-template <int ELEM, int U, int R, int NQ, int SPACE, int S>
+template <int ELEM, int U, int R, int NQ, int SPACE, int S, bool PH = false>
 __global__ __launch_bounds__(kScanThreads) void scan_rows_any(const u32x4* __restrict__ E, int64_t n_rows, int units,
                                                               const float* __restrict__ Q, int n_candidates,
                                                               uint64_t* __restrict__ keys, int64_t keys_per_query) {
   __shared__ MergeShared merge_buf;
-  scan_rows_any_body<ELEM, U, R, NQ, SPACE, S>(E, n_rows, units, Q, n_candidates, keys, keys_per_query, merge_buf);
+  scan_rows_any_body<ELEM, U, R, NQ, SPACE, S, PH>(E, n_rows, units, Q, n_candidates, keys, keys_per_query, merge_buf);
 }
 
 // REPAIR form: every flagged query of a batch, one corpus pass each, in one launch (knn_scan.hip scan_rows_f32_flagged)
@@ -257,22 +352,37 @@ __device__ __forceinline__ float group_sum_f32(float v, int log2p) {
   return v;
 }
 
-template <int ELEM, int R, int NQ, int SPACE, int S>
+// `units`: 16-byte units per row; PH (rows that are not whole units): COLUMNS per row instead, and the planner has made sure that
+// the rows of one load are a multiple of the period G of the rows' offsets — a lane's rows all have the residue sub mod G.
+template <int ELEM, int R, int NQ, int SPACE, int S, bool PH = false>
 __device__ __forceinline__ void scan_short_rows_any_body(const u32x4* __restrict__ E, int64_t n_rows, int units, int log2p,
                                                          const float* __restrict__ Q, int n_candidates,
                                                          uint64_t* __restrict__ keys, int64_t keys_per_query,
                                                          MergeShared& merge_buf) {
   constexpr int kCols = ELEM ? 8 : 4;
+  constexpr int kElemBytes = ELEM ? 2 : 4;
   constexpr bool DENSE = S == 0;
   const int lane = lane_id();
-  const int wave_in_block = static_cast<int>(threadIdx.x) >> 6;
+  const int wave_in_block = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);   // (see scan_rows_any_body)
   const int64_t gwave = static_cast<int64_t>(blockIdx.x) * (kScanThreads / kWave) + wave_in_block;
   const int64_t n_waves = static_cast<int64_t>(gridDim.x) * (kScanThreads / kWave);
-  const int dim = units * kCols;
+  const int dim = PH ? units : units * kCols;
   const int group = 1 << log2p;           // lanes per row
   const int rows_per_load = kWave >> log2p;
   const int sub = lane >> log2p;          // which row of the load
   const int pos = lane & (group - 1);     // which unit of the row
+  int off0 = 0, row_bytes = 0, head_el = 0;
+  [[maybe_unused]] u32x4 keep;            // PH: the row's own columns in this lane's unit
+  if constexpr (PH) {
+    off0 = static_cast<int>(reinterpret_cast<uintptr_t>(E) & 15u);
+    E = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(E) - off0);
+    row_bytes = dim * kElemBytes;
+    const int row_step = 16 >> __builtin_ctz(static_cast<unsigned>(row_bytes) | 16u);
+    const int head = (off0 + (sub & (row_step - 1)) * row_bytes) & 15;
+    head_el = head / kElemBytes;
+    units = (head + row_bytes + 15) >> 4;                  // units THIS lane's rows touch
+    keep = unit_keep_mask<ELEM>(pos * kCols - head_el, dim);
+  }
   const bool act = pos < units;
   const bool holder = pos == group - 1;   // the lane group_sum_f32 leaves the row's score in
 
@@ -280,10 +390,11 @@ __device__ __forceinline__ void scan_short_rows_any_body(const u32x4* __restrict
 #pragma unroll
   for (int qi = 0; qi < NQ; ++qi) {
     const float* qrow = Q + static_cast<int64_t>(qi) * dim;
-    qf[qi].load(qrow, pos, act);
+    if constexpr (PH) qf[qi].load_shifted(qrow, pos * kCols - head_el, dim);
+    else qf[qi].load(qrow, pos, act);
     if constexpr (SPACE == DEWI_SPACE_COSINE) {
-      // every lane group holds a copy of the query: the first one alone feeds the norm
-      const float norm = wave_query_norm(sub == 0 ? qf[qi].sumsq() : 0.0);
+      // every lane group holds a copy of the query: the first one alone feeds the norm (PH: a lane-strided sum of the raw query)
+      const float norm = wave_query_norm(PH ? strided_sumsq(qrow, dim, lane) : (sub == 0 ? qf[qi].sumsq() : 0.0));
       if (norm > 0.f) qf[qi].scale(norm);
     }
     qf[qi].finish();
@@ -297,19 +408,23 @@ __device__ __forceinline__ void scan_short_rows_any_body(const u32x4* __restrict
 
   const int64_t rows_per_step = static_cast<int64_t>(rows_per_load) * R;
   const int64_t n_steps = (n_rows + rows_per_step - 1) / rows_per_step;
+  const int64_t load_units = PH ? (static_cast<int64_t>(rows_per_load) * row_bytes) >> 4 : static_cast<int64_t>(rows_per_load) * units;
   for (int64_t st = gwave; st < n_steps; st += n_waves) {
     const int64_t row_first = st * rows_per_step + sub;
     u32x4 v[R];
+    // (the loads of a step are a whole number of units apart: rows_per_load rows)
+    const u32x4* p = E + (PH ? (off0 + row_first * row_bytes) >> 4 : row_first * units) + pos;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t row = row_first + static_cast<int64_t>(r) * rows_per_load;
       v[r] = u32x4{0u, 0u, 0u, 0u};
-      if (act && row < n_rows) v[r] = load_u4<true>(E + row * units + pos);
+      if (act && row < n_rows) v[r] = load_u4<true>(p + r * load_units);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t row = row_first + static_cast<int64_t>(r) * rows_per_load;
       const bool mine = holder && row < n_rows;
+      if constexpr (PH) v[r] = and_u4(v[r], keep);
 #pragma unroll
       for (int qi = 0; qi < NQ; ++qi) {
         float s = group_sum_f32(qf[qi].dot(v[r], 0.f), log2p);
@@ -343,12 +458,12 @@ __device__ __forceinline__ void scan_short_rows_any_body(const u32x4* __restrict
   }
 }
 
-template <int ELEM, int R, int NQ, int SPACE, int S>
+template <int ELEM, int R, int NQ, int SPACE, int S, bool PH = false>
 __global__ __launch_bounds__(kScanThreads) void scan_short_rows_any(const u32x4* __restrict__ E, int64_t n_rows, int units,
                                                                     int log2p, const float* __restrict__ Q, int n_candidates,
                                                                     uint64_t* __restrict__ keys, int64_t keys_per_query) {
   __shared__ MergeShared merge_buf;
-  scan_short_rows_any_body<ELEM, R, NQ, SPACE, S>(E, n_rows, units, log2p, Q, n_candidates, keys, keys_per_query, merge_buf);
+  scan_short_rows_any_body<ELEM, R, NQ, SPACE, S, PH>(E, n_rows, units, log2p, Q, n_candidates, keys, keys_per_query, merge_buf);
 }
 
 template <int ELEM, int R, int SPACE, int S>
@@ -368,12 +483,13 @@ __global__ __launch_bounds__(kScanThreads) void scan_short_rows_any_flagged(cons
 // ---------------------------------------------------------------------------------------------
 // dispatch (one translation unit per element type instantiates it: knn_scan_any_f32.hip, knn_scan_any_bf16.hip)
 // ---------------------------------------------------------------------------------------------
-template <int ELEM, int NQ, int SPACE, int S>
+template <int ELEM, int NQ, int SPACE, int S, bool PH>
 static hipError_t launch_any_long(const ScanPlan& plan, const u32x4* E, int64_t n_rows, const float* Q, int c, uint64_t* keys,
                                   hipStream_t stream) {
+  const int width = PH ? plan.row_cols : plan.units;
 #define DEWI_ANY_LAUNCH(UU, RR)                                                                                          \
-  hipLaunchKernelGGL((scan_rows_any<ELEM, UU, RR, NQ, SPACE, S>), dim3(plan.blocks), dim3(kScanThreads), 0, stream, E, n_rows, \
-                     plan.units, Q, c, keys, plan.keys_per_query);                                                      \
+  hipLaunchKernelGGL((scan_rows_any<ELEM, UU, RR, NQ, SPACE, S, PH>), dim3(plan.blocks), dim3(kScanThreads), 0, stream, E, n_rows, \
+                     width, Q, c, keys, plan.keys_per_query);                                                           \
   return hipGetLastError();
 #define DEWI_ANY_CASE(UU)                                                                                       \
   case UU:                                                                                                      \
@@ -386,9 +502,10 @@ static hipError_t launch_any_long(const ScanPlan& plan, const u32x4* E, int64_t 
     DEWI_ANY_LAUNCH(UU, any_rows(UU, NQ, 1))
   // Queries per pass by row width (the fragments of NQ queries must fit the registers next to the rows in flight): an fp32
   // unit keeps 4 registers per query, a bf16 unit 4 (cosine, packed pairs) or 8 (l2) — any_nq_max() is the same table
-  constexpr bool kNarrow = ELEM == 0 ? (NQ == 1 || NQ == 4) : true;     // units per lane 1 .. 4 (bf16) / 1 .. 8 (fp32)
-  constexpr bool kMiddle = ELEM == 0 ? (NQ == 1 || NQ == 4) : (NQ == 1 || NQ == 2);   // 5 .. 8
-  constexpr bool kWide = ELEM == 0 ? (NQ == 1 || NQ == 2) : NQ == 1;    // 10 .. 16
+  // (PH, rows that are not whole units: any_nq_max_odd — four queries up to 4 units per lane, one beyond)
+  constexpr bool kNarrow = PH ? (NQ == 1 || NQ == 4) : (ELEM == 0 ? (NQ == 1 || NQ == 4) : true);   // units per lane 1 .. 4 (bf16) / 1 .. 8 (fp32)
+  constexpr bool kMiddle = PH ? NQ == 1 : (ELEM == 0 ? (NQ == 1 || NQ == 4) : (NQ == 1 || NQ == 2));   // 5 .. 8
+  constexpr bool kWide = PH ? NQ == 1 : (ELEM == 0 ? (NQ == 1 || NQ == 2) : NQ == 1);    // 10 .. 16
   if constexpr (kNarrow && NQ != 2) {
     switch (plan.u_pad) {
       DEWI_ANY_CASE(1)
@@ -419,22 +536,23 @@ static hipError_t launch_any_long(const ScanPlan& plan, const u32x4* E, int64_t 
   return hipErrorInvalidValue;
 }
 
-template <int ELEM, int NQ, int SPACE, int S>
+template <int ELEM, int NQ, int SPACE, int S, bool PH>
 static hipError_t launch_any_kind(const ScanPlan& plan, const u32x4* E, int64_t n_rows, const float* Q, int c, uint64_t* keys,
                                   hipStream_t stream) {
   if (plan.kind == kScanAnyShort) {
     if constexpr (NQ == 2) {
       return hipErrorInvalidValue;
     } else {
-      hipLaunchKernelGGL((scan_short_rows_any<ELEM, kAnyShortRows, NQ, SPACE, S>), dim3(plan.blocks), dim3(kScanThreads), 0, stream,
-                         E, n_rows, plan.units, plan.log2p, Q, c, keys, plan.keys_per_query);
+      hipLaunchKernelGGL((scan_short_rows_any<ELEM, kAnyShortRows, NQ, SPACE, S, PH>), dim3(plan.blocks), dim3(kScanThreads), 0, stream,
+                         E, n_rows, PH ? plan.row_cols : plan.units, plan.log2p, Q, c, keys, plan.keys_per_query);
       return hipGetLastError();
     }
   }
-  return launch_any_long<ELEM, NQ, SPACE, S>(plan, E, n_rows, Q, c, keys, stream);
+  return launch_any_long<ELEM, NQ, SPACE, S, PH>(plan, E, n_rows, Q, c, keys, stream);
 }
 
-template <int ELEM>
+// PH = false: rows of whole units (knn_scan_any_*.hip); PH = true: the others (knn_scan_odd_*.hip)
+template <int ELEM, bool PH = false>
 static hipError_t launch_scan_any_impl(const ScanPlan& plan, const void* d_E, int64_t n_rows, int dim, const float* d_q_raw, int q0,
                                        int nq, int n_candidates, int space, uint64_t* d_keys, hipStream_t stream) {
   const u32x4* E = static_cast<const u32x4*>(d_E);
@@ -442,9 +560,9 @@ static hipError_t launch_scan_any_impl(const ScanPlan& plan, const void* d_E, in
   uint64_t* keys = d_keys + static_cast<int64_t>(q0) * plan.keys_per_query;
 #define DEWI_ANY_S(NQ, SPACE)                                                                                        \
   switch (plan.slots) {                                                                                              \
-    case 0: return launch_any_kind<ELEM, NQ, SPACE, 0>(plan, E, n_rows, Q, n_candidates, keys, stream);              \
-    case 1: return launch_any_kind<ELEM, NQ, SPACE, 1>(plan, E, n_rows, Q, n_candidates, keys, stream);              \
-    default: return launch_any_kind<ELEM, NQ, SPACE, kMaxSlots>(plan, E, n_rows, Q, n_candidates, keys, stream);     \
+    case 0: return launch_any_kind<ELEM, NQ, SPACE, 0, PH>(plan, E, n_rows, Q, n_candidates, keys, stream);          \
+    case 1: return launch_any_kind<ELEM, NQ, SPACE, 1, PH>(plan, E, n_rows, Q, n_candidates, keys, stream);          \
+    default: return launch_any_kind<ELEM, NQ, SPACE, kMaxSlots, PH>(plan, E, n_rows, Q, n_candidates, keys, stream); \
   }
 #define DEWI_ANY_Q(NQ)                 \
   if (space == DEWI_SPACE_COSINE) {    \
@@ -455,9 +573,21 @@ static hipError_t launch_scan_any_impl(const ScanPlan& plan, const void* d_E, in
   if (nq == 1) {
     DEWI_ANY_Q(1)
   } else if (nq == 2) {
-    DEWI_ANY_Q(2)
+    if constexpr (!PH) { DEWI_ANY_Q(2) }
   } else if (nq == 4) {
-    DEWI_ANY_Q(4)
+    if constexpr (PH && ELEM == 1) {
+      // bf16 l2 keeps 8 fp32 registers per query and unit next to the masks: four queries spill — one pass per query there
+      if (space != DEWI_SPACE_COSINE) {
+        for (int i = 0; i < 4; ++i) {
+          const hipError_t e = launch_scan_any_impl<ELEM, PH>(plan, d_E, n_rows, dim, d_q_raw, q0 + i, 1, n_candidates, space, d_keys, stream);
+          if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+      }
+      DEWI_ANY_S(4, DEWI_SPACE_COSINE)
+    } else {
+      DEWI_ANY_Q(4)
+    }
   }
 #undef DEWI_ANY_Q
 #undef DEWI_ANY_S

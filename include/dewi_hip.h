@@ -108,6 +108,10 @@ int dewi_payload_soa_f64(const double* d_dewi, const double* d_ht_mean, const do
  *      adj += fp32(pref)*ent32[i]   if pref != 0           (:464-465)
  *   5. k best by adj, descending                           (:468-481)   ties: higher sim, then lower row
  * d_E  [n_rows][dim] row-major; d_Q [n_queries][dim] raw (un-normalised) fp32 queries.
+ *      ANY dim, as the reference's one BLAS call (:431-433).  Rows that are whole 16-byte units (fp32 dim % 4 == 0, bf16
+ *      dim % 8 == 0): d_E 16-byte aligned (hipMalloc gives 256).  Other widths: d_E may be any element-aligned address — a
+ *      shard that starts in the middle of a larger buffer; the kernels read whole aligned 16-byte units, so up to 15 bytes
+ *      before the first and behind the last row are touched (never across a 16-byte boundary, hence never across a page).
  * d_out_ids [n_queries][k] int64 row indices, d_out_scores [n_queries][k] fp32.
  * k <= 0 writes nothing and returns DEWI_OK (reference returns []); k > n_rows returns
  * DEWI_ERR_K_OUT_OF_BOUNDS (reference: ValueError from np.argpartition).
@@ -122,8 +126,8 @@ int dewi_payload_soa_f64(const double* d_dewi, const double* d_ht_mean, const do
 size_t dewi_knn_workspace_bytes(int64_t n_rows, int dim, int n_queries, int n_candidates);
 
 /* Name of the kernel that streams the corpus for this shape on the calling thread's current device and tuning, as
- * rocprofv3 prints it up to its template arguments ("scan_rows_f32", "scan_rows_any<0, 2, 3, 1, 0, 1>",
- * "scan_short_rows_any<0, 8, 1, 0, 1>", "scan_generic_f32", "mfma_scan_f32<false", "mfma_scan_bf16_s16"): what a
+ * rocprofv3 prints it up to its template arguments ("scan_rows_f32", "scan_rows_any<0, 2, 3, 1, 0, 1, false>",
+ * "scan_short_rows_any<0, 8, 1, 0, 1, false>", "scan_generic_f32", "mfma_scan_f32<false", "mfma_scan_bf16_s16"): what a
  * measurement harness labels its roofline line with.  (ABI 5.) */
 int dewi_knn_scan_kernel(int elem_type, int64_t n_rows, int dim, int n_queries, int n_candidates, int space, char* out,
                          size_t out_bytes);

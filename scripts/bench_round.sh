@@ -16,7 +16,8 @@ run c2_steps20_condition0 --steps 20 --warmup 5 --condition-ms 0
 # other embedding widths at equal corpus bytes (~3 GB, one query per step): the any-width row kernels
 # (--cpu-queries 64: the parity gate — 64 queries against the oracle — runs in these lines too; the CPU figure they carry is a
 # 64-query sample of THAT workload, not the headline's baseline)
-for d in 128 384 1000 1280 3072; do
+# (50, 129, 301, 1001: rows that are not whole 16-byte units)
+for d in 128 384 1000 1280 3072 50 129 301 1001; do
   run dim$d --dim $d --docs $(( 3072000000 / (4 * d) )) --cpu-queries 64
 done
 run dim384_batch4 --dim 384 --docs 2000000 --batch 4 --cpu-queries 64

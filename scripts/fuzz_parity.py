@@ -37,8 +37,10 @@ args = ap.parse_args()
 rs = np.random.RandomState(args.seed)
 # (round 4: every kind of row kernel — lanes sharing a short row, one row per step with a predicated tail at every
 # instantiated units-per-lane count for fp32 and bf16, the scalar-capable generic kernel, the tuned dim = 256 U ones)
-DIMS = [1, 3, 4, 8, 12, 17, 36, 64, 100, 128, 132, 200, 252, 256, 260, 300, 384, 512, 640, 768, 1000, 1024, 1280, 1536, 1792, 2048,
-        2304, 3072, 4096]
+# (and rows that are not whole 16-byte units: fp32 dim % 4 != 0 / bf16 dim % 8 != 0 — 1, 3, 17, 50, 101, 129, 301, 770, 1001, 2050, 3001;
+# bf16 also 12, 36, 100, 132, 252, 260, 300)
+DIMS = [1, 3, 4, 8, 12, 17, 36, 50, 64, 100, 101, 128, 129, 132, 200, 252, 256, 260, 300, 301, 384, 512, 640, 768, 770, 1000, 1001,
+        1024, 1280, 1536, 1792, 2048, 2050, 2304, 3001, 3072, 4096]
 fails, done = [], {"search": 0, "shards": 0, "fit": 0}
 LAST = {}
 

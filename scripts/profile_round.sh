@@ -45,7 +45,8 @@ probe_pmc() {     # dir suffix, counters, probe args...
 }
 trace c2 --steps 300 --warmup 30
 # other embedding widths at equal corpus bytes (~3 GB): the any-width row kernels (csrc/scan_any.hpp), round 4
-DIMS="128 384 1000 1280 3072"
+# (301, 1001: rows that are not whole 16-byte units — the PH = true form; their traffic includes the re-read boundary units)
+DIMS="128 384 1000 1280 3072 301 1001"
 for d in $DIMS; do
   rows=$(( 3072000000 / (4 * d) ))
   trace dim$d --dim $d --docs $rows --steps 200 --warmup 20
@@ -78,8 +79,9 @@ probe_pmc WRITE_SIZE_f32b32 WRITE_SIZE 32
 probe_pmc SQ_WAIT_f32b32 "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_WR" 32
 probe_pmc WRITE_SIZE_bf16b32 WRITE_SIZE --bf16 32
 python3 scripts/summarize_pmc.py $OUT --commit $COMMIT --record "1000000x768x4xB1=scan_rows_f32" "1000000x768x2xB256=mfma_scan_bf16_s16<48, false>" \
-  "6000000x128x4xB1=scan_short_rows_any<0, 8, 1, 0, 1>" "2000000x384x4xB1=scan_rows_any<0, 2, 3, 1, 0, 1>" "768000x1000x4xB1=scan_rows_any<0, 4, 1, 1, 0, 1>" \
-  "600000x1280x4xB1=scan_rows_any<0, 5, 1, 1, 0, 1>" "250000x3072x4xB1=scan_rows_any<0, 12, 1, 1, 0, 1>" \
+  "6000000x128x4xB1=scan_short_rows_any<0, 8, 1, 0, 1, false>" "2000000x384x4xB1=scan_rows_any<0, 2, 3, 1, 0, 1, false>" "768000x1000x4xB1=scan_rows_any<0, 4, 1, 1, 0, 1, false>" \
+  "600000x1280x4xB1=scan_rows_any<0, 5, 1, 1, 0, 1, false>" "250000x3072x4xB1=scan_rows_any<0, 12, 1, 1, 0, 1, false>" \
+  "2551495x301x4xB1=scan_rows_any<0, 2, 4, 1, 0, 1, true>" "767232x1001x4xB1=scan_rows_any<0, 4, 1, 1, 0, 1, true>" \
   "1000000x768x4xB32=mfma_scan_f32<false, 3, false, false, false>" "1000000x768x2xB32=mfma_scan_f32<true, 3, false, false, false>" \
   "1000000x768x2xB1=scan_rows_bf16<3, 1, 0, 1, true>" \
   "rowcos_1000000x512=row_cosine_512_kernel<2>" "fit_med_7x1000000=fit_fast_kernel<false>" "fit_mad_7x1000000=fit_fast_kernel<true>" > $OUT/pmc_summary.txt

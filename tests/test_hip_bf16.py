@@ -36,8 +36,8 @@ def _setup(n, dim, seed):
                                    (1000, 1501), (3072, 800), (5120, 502), (8192, 301), (8200, 300)])
 def test_bf16_search_vs_oracle(dim, n):
     """Pair-of-rows kernel (dim = 256*H, odd and even row counts); the any-width kernels (dim % 8 == 0: rows sharing a wave up
-    to 256 columns, one row per step with a predicated tail up to 8192, two queries per pass beyond 4096); scalar generic (100)
-    and the 16-byte generic beyond 8192 columns (8200)."""
+    to 256 columns, one row per step with a predicated tail up to 8192, two queries per pass beyond 4096); rows that are not whole
+    units (100: tests/test_hip_odd_rows.py has the sweep) and the 16-byte generic kernel beyond 8192 columns (8200)."""
     cb, Eb, dewi32, ent32 = _setup(n, dim, seed=dim + n)
     Q = orc.synth_queries(5, dim, seed=dim)
     Qp = device_prepared_queries(Q)

@@ -157,7 +157,8 @@ def test_dimension_sweep_vs_oracle(dim):
     """Every row-kernel variant: the tuned widths (dim = 256*U), the any-width kernels of scan_any.hpp — short rows sharing a
     wave (dim <= 128: 1, 2, 4 ... 32 lanes per row, with idle lanes at 12 / 36 / 100), one row per step with a predicated tail
     (132 ... 4096: every instantiated units-per-lane count, 1792 and 2304 on a padded one), two queries per pass beyond
-    2048 columns — and the scalar-capable generic kernel (dim % 4 != 0: 10; beyond 4096 columns: 4100)."""
+    2048 columns — the form of those kernels for rows that are not whole units (dim % 4 != 0: 10; tests/test_hip_odd_rows.py
+    has the sweep of those) and the generic kernel (beyond 4096 columns: 4100)."""
     n = 3001 if dim <= 1024 else 1500
     raw = orc.synth_corpus(n, dim, seed=dim)
     cols = orc.synth_payload_columns(n, seed=dim)
