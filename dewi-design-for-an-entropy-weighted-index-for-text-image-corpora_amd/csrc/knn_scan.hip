@@ -426,7 +426,12 @@ ScanPlan plan_scan(int64_t n_rows, int dim, int elem_bytes, int n_candidates, in
       for (int v : pads)
         if (v >= need) { p.u_pad = v; break; }
       p.nq_max = any_nq_max_odd(p.u_pad);
-      p.level = tuning.rows_per_iter > 0 ? (tuning.rows_per_iter - 1) % kAnyLevels : any_level(most_units);
+      // (rows in flight by the bytes a row HAS — (row_bytes + 15) / 16 units — not by the units it can touch — and one choice
+      // further towards more rows: a wave's rows lie row_step rows apart here.  3 GB, TB/s by level: dim 161 6.18 / 6.01 / 6.01,
+      // 301 6.56 / 6.48 / 6.03, 387 6.64 / 6.62 / 6.65, 1001 6.79 / 6.72 / 6.72; profiles/r04/odd_rows/sweep_levels.txt)
+      int level = any_level((row_bytes + 15) / 16);
+      if (level > 0) --level;
+      p.level = tuning.rows_per_iter > 0 ? (tuning.rows_per_iter - 1) % kAnyLevels : level;
       p.rows_per_iter = any_rows(p.u_pad, 1, p.level);
       p.rows_per_iter_batch = any_rows(p.u_pad, p.nq_max, p.level);
     }
