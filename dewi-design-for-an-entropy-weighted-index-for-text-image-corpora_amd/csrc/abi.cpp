@@ -429,11 +429,11 @@ ShadowPlan plan_shadow(bool have_shadow, int64_t n_rows, int dim, int n_queries,
   // 16-byte units per lane in the re-scoring); everything else is the plain search.  dim 1024 / 1536 have no 256-query pass
   // (and 1536 no tuned bf16 row kernel: one query takes the depth-split pass too):
   // its batches run the depth-split pass over the shadow in groups of 32 (2 GB instead of 4 GB per group at 1 M rows)
-  // (round 4: every dim % 32 == 0 from 160 to 1536 columns — the re-scoring repeats scan_rows_any's arithmetic at the widths
-  // outside the dim = 256 U set, and the depth-split pass takes a partial last chunk; below 160 columns the one-query kernel
-  // is scan_short_rows_any, whose lane layout the re-scoring does not repeat)
+  // (round 4: every dim % 8 == 0 — whole 16-byte units of the bf16 copy — from 136 to 1536 columns: the re-scoring repeats
+  // scan_rows_any's arithmetic at the widths outside the dim = 256 U set, and the depth-split pass takes a partial last chunk;
+  // up to 128 columns the one-query kernel is scan_short_rows_any, whose lane layout the re-scoring does not repeat)
   const bool usable = have_shadow && g_tuning.mfma != 0 && space == DEWI_SPACE_COSINE && k > 0 && k <= n_rows &&
-                      dim % 32 == 0 && dim >= 160 && dim <= 1536;
+                      dim % 8 == 0 && dim >= 136 && dim <= 1536;
   if (!usable) return S;
   const bool use_big = n_queries > 32 && c64 <= 512 && dewi::mfma_path_supported(n_rows, dim, n_queries, S.c, space);
   // (a SINGLE query takes the depth-split pass too: one pass over half the bytes + the exact re-scoring, 0.26 ms instead of

@@ -156,27 +156,29 @@ __device__ __forceinline__ void split3(const u32x4f& x0, const u32x4f& x1, u32x4
 // L2: the score is -||e - q||^2 (reference backends.py:434-436) in the form 2<e,q> - ||e||^2 - ||q||^2: Qn holds the raw
 //     (bf16 corpus: bf16-rounded) queries, qn2 their squared norms, and ||e||^2 is summed here from the very fragments
 //     that are multiplied (see "row norms" below).
-// PARTIAL (round 4): the row's LAST chunk holds only 32 * vw of its 256 columns (dim = 256 (CH - 1) + 32 vw, vw = 1..7), so
-//     that every dim % 32 == 0 takes this pass, not only whole chunks.  Wave w multiplies columns [32 w, 32 w + 32) of a chunk:
-//     in the last chunk the waves w >= vw have nothing of this row — they still move their DMA pieces (a piece of the partial
-//     chunk carries the head of the NEXT row behind the row's tail; past the tile's last row the buffer descriptor returns
-//     zeros) and keep every barrier, but skip their matrix instructions: a NaN in the neighbouring row must not reach this
-//     row's score through a 0 x NaN product.  Row stride and query stride become run-time values.  Cosine, and l2 over an fp32
-//     corpus (exact-refine mode: the select re-scores with scan_rows_any's arithmetic, widths from 160 columns).
+// PARTIAL (round 4): the row's LAST chunk holds only last_cols of its 256 columns (dim = 256 (CH - 1) + last_cols; whole 16-byte
+//     units: a multiple of 4 columns of fp32, 8 of bf16), so that every such dim takes this pass, not only whole chunks.  Wave w
+//     multiplies columns [32 w, 32 w + 32) of a chunk: in the last chunk the waves with 32 w >= last_cols have nothing of this row —
+//     they still keep every barrier, but skip their matrix instructions — and the ONE wave whose slice the row ends in clears
+//     the fragment units behind the row's end (DMA lanes behind the end move nothing, so those LDS bytes are whatever an
+//     earlier chunk left there): a NaN there must not reach this row's score through a 0 x NaN product.  Row stride and query
+//     stride become run-time values.  Cosine, and l2 over an fp32 corpus (exact-refine mode: the select re-scores with
+//     scan_rows_any's arithmetic, widths from 132 columns = 33 units).
 template <bool BF16, int CH, bool SAMPLE, bool L2, bool PARTIAL = false>
 __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __restrict__ E, int64_t n_rows,
                                                                 const void* __restrict__ Qn, int64_t n_tiles,
                                                                 int64_t tile_stride, const float* __restrict__ thr,
                                                                 uint64_t* __restrict__ out, int64_t out_stride,
                                                                 uint32_t* __restrict__ cnt, int n_active,
-                                                                const float* __restrict__ qn2, float aux, int vw) {
+                                                                const float* __restrict__ qn2, float aux, int last_cols) {
   // aux: l2 — the error bound per unit of ||e||^2 + ||q||^2 (exact-refine mode, 0 = unrefined); cosine — a bias subtracted
   // from every threshold (0, or two error bounds when the pass pre-selects over the bf16 shadow of an fp32 corpus)
 #if defined(__HIP_DEVICE_COMPILE__)
   const float l2_margin = L2 ? aux : 0.f;
   using G = DepthGeo<BF16>;
   static_assert(!(PARTIAL && L2 && BF16), "partial last chunk + l2: fp32 corpora (exact-refine mode) only");
-  const int DIM = PARTIAL ? (CH - 1) * kF32ChunkCols + 32 * vw : CH * kF32ChunkCols;   // compile-time unless PARTIAL
+  const int DIM = PARTIAL ? (CH - 1) * kF32ChunkCols + last_cols : CH * kF32ChunkCols;   // compile-time unless PARTIAL
+  constexpr int kUnitCols = BF16 ? 8 : 4;                      // columns per 16-byte unit
   constexpr int RM = G::kRing - 1;                             // ring slot of chunk g: g & RM
   extern __shared__ __attribute__((aligned(16))) char lds[];   // ring | partial sums | per-query counters
   float* const red = reinterpret_cast<float*>(lds + G::kRing * G::kChunk);
@@ -195,12 +197,13 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
 #pragma unroll
   for (int ch = 0; ch < CH; ++ch) {
     u32x4f raw[G::kReads];
-    const bool dead = PARTIAL && ch == CH - 1 && w >= vw;      // wave-uniform: no columns of the row in this wave's slice
 #pragma unroll
     for (int m = 0; m < G::kReads; ++m) {
       const char* qrow = static_cast<const char*>(Qn) + static_cast<int64_t>(r) * DIM * G::kElem;
       raw[m] = u32x4f{0u, 0u, 0u, 0u};
-      if (!dead) raw[m] = *reinterpret_cast<const u32x4f*>(qrow + kF32ChunkCols * G::kElem * ch + 32 * G::kElem * w + 16 * (2 * m + h));
+      // (PARTIAL, last chunk: units behind the row's end stay zero — whole waves, and the tail of the wave the row ends in)
+      const bool behind = PARTIAL && ch == CH - 1 && 32 * w + kUnitCols * (2 * m + h) >= last_cols;
+      if (!behind) raw[m] = *reinterpret_cast<const u32x4f*>(qrow + kF32ChunkCols * G::kElem * ch + 32 * G::kElem * w + 16 * (2 * m + h));
     }
     if constexpr (kSplit) {
       split3(raw[0], raw[1], qf[ch][0], qf[ch][1], qf[ch][2]);
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
   // PARTIAL: in the row's last chunk only the lanes whose SOURCE unit lies inside the row fetch (EXEC-masked DMA: the other
   // lanes move nothing and leave their LDS bytes as they are — only the waves that skip the chunk would read those).  Without the
   // mask a piece carried the head of the next row behind the row's tail: dim 128 moved every byte twice (pass 0.91 ms per 3 GB).
-  const uint32_t valid_units = PARTIAL ? static_cast<uint32_t>(vw) * (BF16 ? 4u : 8u) : 64u;
+  const uint32_t valid_units = PARTIAL ? static_cast<uint32_t>(last_cols / kUnitCols) : 64u;
   const bool in_row_even = BF16 ? ((static_cast<uint32_t>(lane & 31) ^ (row_b & 15u)) < valid_units)
                                 : (static_cast<uint32_t>(lane ^ w) < valid_units);
   const bool in_row_odd = BF16 ? in_row_even : (static_cast<uint32_t>(lane ^ (w + 8)) < valid_units);
@@ -559,7 +562,13 @@ __global__ __launch_bounds__(kF32Threads, 2) void mfma_scan_f32(const void* __re
       const __amdgpu_buffer_rsrc_t rs4 = tile_rsrc(it + (ch + G::kRing) / CH);
       __builtin_amdgcn_sched_barrier(0);
       const f32x16f zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      const bool skip = PARTIAL && ch == CH - 1 && w >= vw;   // wave-uniform (PARTIAL: see the kernel's header)
+      const bool skip = PARTIAL && ch == CH - 1 && 32 * w >= last_cols;   // wave-uniform (PARTIAL: see the kernel's header)
+      if (PARTIAL && ch == CH - 1 && !skip && 32 * w + 32 > last_cols) {  // wave-uniform: the row ends inside this wave's slice
+#pragma unroll
+        for (int m = 0; m < G::kReads; ++m) {
+          if (32 * w + kUnitCols * (2 * m + h) >= last_cols) cur[m] = u32x4f{0u, 0u, 0u, 0u};
+        }
+      }
       if (skip) {
         if (ch == 0) {                                        // a one-chunk row: this wave contributes nothing at all
           acc = zero;
@@ -676,11 +685,12 @@ bool mfma_f32_path_supported(int elem_type, int64_t n_rows, int dim, int n_queri
   if ((space != DEWI_SPACE_COSINE && space != DEWI_SPACE_L2) || n_queries < min_q || n_rows < 64 * 1024 || n_candidates > 256 || dim <= 0)
     return false;
   if (dim % kF32ChunkCols != 0) {
-    // a partial last chunk (round 4): any dim % 32 == 0 up to 1536 columns, cosine; l2 over an fp32 corpus (exact-refine mode) from
-    // 160 columns (below, the one-query kernel is scan_short_rows_any, whose arithmetic the re-scoring does not repeat) to 768
-    if (dim % 32 != 0 || dim >= 6 * kF32ChunkCols) return false;
+    // a partial last chunk (round 4): rows of whole 16-byte units (fp32 dim % 4 == 0, bf16 dim % 8 == 0) from 32 up to 1536 columns,
+    // cosine; l2 over an fp32 corpus (exact-refine mode) from 132 columns = 33 units (below, the one-query kernel is
+    // scan_short_rows_any, whose arithmetic the re-scoring does not repeat) to 768
+    if (dim % (elem_type ? 8 : 4) != 0 || dim < 32 || dim >= 6 * kF32ChunkCols) return false;
     if (space == DEWI_SPACE_COSINE) return true;
-    return elem_type == 0 && dim >= 160 && dim < kF32MaxL2Chunks * kF32ChunkCols;
+    return elem_type == 0 && dim >= 132 && dim < kF32MaxL2Chunks * kF32ChunkCols;
   }
   const int ch = dim / kF32ChunkCols;
   if (space == DEWI_SPACE_L2) {
@@ -726,13 +736,13 @@ MfmaF32Layout plan_mfma_f32(int elem_type, int64_t n_rows, int dim, int n_querie
   return m;
 }
 
-// PARTIAL: dim = 256 (CH - 1) + 32 vw (see the kernel); otherwise dim = 256 CH and vw is ignored
+// PARTIAL: dim = 256 (CH - 1) + last_cols (see the kernel); otherwise dim = 256 CH and last_cols is ignored
 template <bool BF16, int CH, bool L2, bool PARTIAL = false>
 static hipError_t run_mfma_f32_dim(const MfmaF32Layout& m, const void* E, int64_t n_rows, int n_queries, int n_candidates,
-                                   char* ws, hipStream_t stream, float thr_bias, int vw = 8) {
+                                   char* ws, hipStream_t stream, float thr_bias, int last_cols = kF32ChunkCols) {
   // l2 over an fp32 corpus runs in exact-refine mode (see stage2_finish and select_rerank.hip): error bound per unit of
   // ||e||^2 + ||q||^2.  bf16 corpora (opt-in, approximate) and cosine: no margin.
-  const int DIM = PARTIAL ? (CH - 1) * kF32ChunkCols + 32 * vw : CH * kF32ChunkCols;
+  const int DIM = PARTIAL ? (CH - 1) * kF32ChunkCols + last_cols : CH * kF32ChunkCols;
   const float l2_margin = L2 ? (BF16 ? 0.f : depth_l2_margin(DIM)) : thr_bias;   // the kernel's `aux`
   constexpr int kLds = depth_lds_bytes<BF16>();
   static PerDeviceOnce attr_once;   // one per instantiation
@@ -760,7 +770,7 @@ static hipError_t run_mfma_f32_dim(const MfmaF32Layout& m, const void* E, int64_
     const float* q2g = qn2 + g * kF32Queries;
     hipLaunchKernelGGL((mfma_scan_f32<BF16, CH, true, L2, PARTIAL>), dim3(m.sample_blocks), dim3(kF32Threads), kLds, stream, E, n_rows, qg,
                        m.n_sample_tiles, m.tile_stride, static_cast<const float*>(nullptr), reinterpret_cast<uint64_t*>(dense),
-                       m.sample_stride, static_cast<uint32_t*>(nullptr), n_active, q2g, l2_margin, vw);
+                       m.sample_stride, static_cast<uint32_t*>(nullptr), n_active, q2g, l2_margin, last_cols);
     // 2. per-query threshold: the c-th largest group maximum (real queries only)
     const hipError_t et = launch_sample_threshold(dense, m.sample_stride, m.sample_stride, n_candidates, tg, n_active, stream);
     if (et != hipSuccess) return et;
@@ -768,7 +778,7 @@ static hipError_t run_mfma_f32_dim(const MfmaF32Layout& m, const void* E, int64_
     timing_begin(stream);
     hipLaunchKernelGGL((mfma_scan_f32<BF16, CH, false, L2, PARTIAL>), dim3(m.n_blocks), dim3(kF32Threads), kLds, stream, E, n_rows, qg,
                        m.n_tiles, static_cast<int64_t>(1), static_cast<const float*>(tg), og, static_cast<int64_t>(m.seg_cap), cg,
-                       n_active, q2g, l2_margin, vw);
+                       n_active, q2g, l2_margin, last_cols);
     timing_end(stream);
   }
   return hipGetLastError();
@@ -797,21 +807,21 @@ hipError_t launch_mfma_f32(const MfmaF32Layout& m, int elem_type, const void* d_
     return elem_type ? run_mfma_f32_dim<true, CH, false>(m, d_E, n_rows, n_queries, n_candidates, ws, stream, thr_bias)      \
                      : run_mfma_f32_dim<false, CH, false>(m, d_E, n_rows, n_queries, n_candidates, ws, stream, thr_bias);
   if (dim % kF32ChunkCols != 0) {      // a partial last chunk (mfma_f32_path_supported)
-    if (dim % 32 != 0) return hipErrorInvalidValue;
-    const int vw = (dim % kF32ChunkCols) / 32;
+    if (dim % (elem_type ? 8 : 4) != 0) return hipErrorInvalidValue;
+    const int last_cols = dim % kF32ChunkCols;
     if (l2) {                          // fp32 corpus, exact-refine mode, up to three chunks
       if (elem_type) return hipErrorInvalidValue;
       switch (dim / kF32ChunkCols + 1) {
-        case 1: return run_mfma_f32_dim<false, 1, true, true>(m, d_E, n_rows, n_queries, n_candidates, ws, stream, 0.f, vw);
-        case 2: return run_mfma_f32_dim<false, 2, true, true>(m, d_E, n_rows, n_queries, n_candidates, ws, stream, 0.f, vw);
-        case 3: return run_mfma_f32_dim<false, 3, true, true>(m, d_E, n_rows, n_queries, n_candidates, ws, stream, 0.f, vw);
+        case 1: return run_mfma_f32_dim<false, 1, true, true>(m, d_E, n_rows, n_queries, n_candidates, ws, stream, 0.f, last_cols);
+        case 2: return run_mfma_f32_dim<false, 2, true, true>(m, d_E, n_rows, n_queries, n_candidates, ws, stream, 0.f, last_cols);
+        case 3: return run_mfma_f32_dim<false, 3, true, true>(m, d_E, n_rows, n_queries, n_candidates, ws, stream, 0.f, last_cols);
         default: return hipErrorInvalidValue;
       }
     }
 #define DEWI_DEPTH_PARTIAL(CH)                                                                                                  \
   case CH:                                                                                                                      \
-    return elem_type ? run_mfma_f32_dim<true, CH, false, true>(m, d_E, n_rows, n_queries, n_candidates, ws, stream, thr_bias, vw) \
-                     : run_mfma_f32_dim<false, CH, false, true>(m, d_E, n_rows, n_queries, n_candidates, ws, stream, thr_bias, vw);
+    return elem_type ? run_mfma_f32_dim<true, CH, false, true>(m, d_E, n_rows, n_queries, n_candidates, ws, stream, thr_bias, last_cols) \
+                     : run_mfma_f32_dim<false, CH, false, true>(m, d_E, n_rows, n_queries, n_candidates, ws, stream, thr_bias, last_cols);
     switch (dim / kF32ChunkCols + 1) {
       DEWI_DEPTH_PARTIAL(1)
       DEWI_DEPTH_PARTIAL(2)

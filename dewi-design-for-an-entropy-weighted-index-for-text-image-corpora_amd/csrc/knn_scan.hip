@@ -556,9 +556,9 @@ static hipError_t launch_flagged_s(const ScanPlan& plan, const float* E, int64_t
 bool scan_flagged_supported(const ScanPlan& plan, int elem_bytes) {
   (void)elem_bytes;
   if (plan.kind == kScanFast) return true;
-  // any-width kernels: the widths the matrix-core passes run at outside the dim = 256 U set — dim % 32 == 0 up to 1536
+  // any-width kernels: the widths the matrix-core passes run at outside the dim = 256 U set — rows of whole units up to 1536
   // columns (the depth-split pass with a partial last chunk), 1280 / 2048, bf16 also 3072 / 4096 (512 units per row)
-  // (rows that are not whole units never meet a matrix-core pass: those need dim % 32 == 0)
+  // (rows that are not whole units never meet a matrix-core pass: those take whole 16-byte units)
   return !plan.odd_rows && (plan.kind == kScanAnyShort || (plan.kind == kScanAnyLong && plan.u_pad <= 8));
 }
 

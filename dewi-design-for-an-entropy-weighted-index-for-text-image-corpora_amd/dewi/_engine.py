@@ -105,14 +105,14 @@ class DeviceCorpus:
         """Keep a bf16 copy of this fp32 matrix next to it (+50 % memory).  Batches of 2 or more cosine queries then run the
         matrix-core passes over the copy as a PRE-SELECTION — half the bytes, and 256 queries per corpus pass instead of
         32 for larger batches — and re-score the candidates from the fp32 rows with the row kernels' arithmetic
-        (``dewi_knn_rerank_f32_shadow``): results equal the one-query search bit for bit.  Every dim % 32 == 0 from 160 to 1536 columns, >= 64 K
+        (``dewi_knn_rerank_f32_shadow``): results equal the one-query search bit for bit.  Every dim % 8 == 0 from 136 to 1536 columns, >= 64 K
         rows; any other shape simply takes the usual path.
 
         ``single_query=True`` sends one-query searches through the shadow as well (k <= 16: the bf16 row kernel with
         per-workgroup lists long enough for the error band, 0.24 ms instead of 0.43 at 1 M x 768; larger k: the pass with one
-        active query, 0.26 ms; same re-scoring, same answers).  Off by default: ``search_device`` with one query is then no
-        longer "always answered" — like any matrix-core batch it may come back refused (id -1) on adversarial corpora;
-        the blocking ``search`` and ``PipelinedSearcher.drain`` repair such a query on the plain fp32 scan."""
+        active query, 0.26 ms; same re-scoring, same answers).  Off by default (+50 % memory for a path the plain scan already
+        serves at the HBM rate); a query the pass refuses on an adversarial corpus is repaired inside the library call like
+        any matrix-core batch (ABI 5)."""
         torch = _torch()
         if self.is_bf16:
             raise ValueError("the corpus is already bf16")

@@ -27,6 +27,9 @@ run dim640_batch32 --dim 640 --docs 1200000 --batch 32 --steps 300 --warmup 60 -
 run dim128_batch32 --dim 128 --docs 6000000 --batch 32 --steps 300 --warmup 60 --cpu-queries 64
 run dim1280_batch32 --dim 1280 --docs 600000 --batch 32 --steps 300 --warmup 60 --cpu-queries 64
 run dim2048_batch32 --dim 2048 --docs 375000 --batch 32 --steps 300 --warmup 60 --cpu-queries 64
+# rows that end inside a wave's 32-column slice of the depth-split pass (dim % 4 == 0, not % 32)
+run dim1000_batch32 --dim 1000 --docs 768000 --batch 32 --steps 300 --warmup 60 --cpu-queries 64
+run dim300_batch32 --dim 300 --docs 2560000 --batch 32 --steps 300 --warmup 60 --cpu-queries 64
 # fp32 corpus + bf16 shadow at widths outside the dim = 256 U set (round 4)
 run dim384_batch256_shadow --dim 384 --docs 2000000 --batch 256 --steps 200 --warmup 40 --cpu-queries 64
 run dim384_batch32_shadow --dim 384 --docs 2000000 --batch 32 --shadow 1 --steps 200 --warmup 40 --cpu-queries 64

@@ -48,7 +48,9 @@ LAST = {}
 def one_search_case(i):
     if args.big:
         # (round 4: widths with a partial last chunk on the depth-split pass — 96, 160, 320, 384, 640, 896, 992)
-        dim = int(rs.choice([96, 128, 160, 256, 256, 320, 384, 384, 512, 512, 640, 768, 768, 768, 896, 992, 1024, 1280, 1312, 1536, 2048]))
+        # (... and rows that end inside a wave's 32-column slice: 100, 200, 300, 1000, 1004, 36)
+        dim = int(rs.choice([96, 128, 160, 256, 256, 320, 384, 384, 512, 512, 640, 768, 768, 768, 896, 992, 1024, 1280, 1312, 1536, 2048,
+                             100, 200, 300, 1000, 1004, 36]))
         n = int(rs.randint(65_536, 160_000))
         bf16 = bool(rs.rand() < 0.45)
         space = "l2" if rs.rand() < 0.2 else "cosine"
@@ -80,7 +82,7 @@ def one_search_case(i):
         kw = dict(gap=1e-6, score_tol=1e-5, prepared=True)
     else:
         E, Qo = c.emb.cpu().numpy(), Q
-        if space == "cosine" and dim % 32 == 0 and 160 <= dim <= 1536 and rs.rand() < 0.7:
+        if space == "cosine" and dim % 8 == 0 and 136 <= dim <= 1536 and rs.rand() < 0.7:
             c.enable_bf16_shadow(single_query=True)   # matrix-core pass over the bf16 shadow + exact re-scoring (1+ queries)
             LAST.update(shadow=True)
             done["shadow"] = done.get("shadow", 0) + 1

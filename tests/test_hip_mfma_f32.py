@@ -46,11 +46,15 @@ def _corpus(n, dim, seed):
 @pytest.mark.parametrize("dim,n,b,k", [(768, 70_001, 32, 10), (768, 66_000, 5, 10), (512, 80_000, 70, 10),
                                        (256, 131_073, 33, 100), (1024, 65_536, 8, 10), (1536, 65_600, 17, 10),
                                        (768, 300_000, 64, 128),
-                                       # round 4: a PARTIAL last chunk — any dim % 32 == 0 up to 1024 columns takes the pass
+                                       # round 4: a PARTIAL last chunk — rows of whole 16-byte units up to 1536 columns take the pass
                                        (384, 70_001, 32, 10), (640, 66_000, 12, 10), (96, 100_000, 7, 10), (992, 65_600, 33, 10),
                                        (160, 70_000, 64, 100), (32, 66_000, 5, 10),
                                        # ... and 1280 / 2048 columns (whole chunks, fp32 instruction as at 1536), 1312 = five chunks + one wave
-                                       (1280, 66_000, 12, 10), (1312, 65_600, 7, 10), (2048, 65_600, 8, 10)])
+                                       (1280, 66_000, 12, 10), (1312, 65_600, 7, 10), (2048, 65_600, 8, 10),
+                                       # ... and rows that END INSIDE a wave's 32-column slice (dim % 4 == 0, not % 32): 300 (12 columns
+                                       # into wave 1), 100, 1000, 36, 260 / 1284 (one unit into a new chunk), 252 (wave 7 four short)
+                                       (300, 70_001, 32, 10), (100, 100_000, 7, 10), (1000, 65_600, 33, 10), (36, 66_000, 5, 10),
+                                       (260, 70_000, 12, 10), (1284, 65_600, 6, 10), (252, 66_000, 40, 50)])
 def test_mfma_f32_batched_vs_oracle(dim, n, b, k):
     import torch
     from dewi import _engine as eng
@@ -111,12 +115,15 @@ def test_mfma_f32_a_batch_of_four_stays_on_the_scan_kernels_and_agrees():
     check_batch(E, Q, dewi32, ent32, 10, 0.3, 0.0, "cosine", ids12, sc12, exact_gaps=False)
 
 
-@pytest.mark.parametrize("bf16", [False, True])
-@pytest.mark.parametrize("dim", [384, 96, 800])
+@pytest.mark.parametrize("dim,bf16", [(384, False), (384, True), (96, False), (96, True), (800, False), (800, True),
+                                       # rows that end inside a wave's slice: the units behind the end are cleared in registers
+                                       (200, False), (200, True), (1000, False), (1000, True), (300, False), (100, False), (260, False),
+                                       (1284, False)])
 def test_partial_chunk_keeps_a_nan_row_out_of_its_neighbours(dim, bf16):
-    """dim % 256 != 0: the DMA piece of a row's partial last chunk carries the head of the NEXT row; the waves whose columns
-    lie past the row skip their matrix instructions, so a NaN row (a zero embedding: 0/0, as in the reference) must not turn
-    the row stored in front of it into NaN.  The NaN row itself ranks first for every query (NumPy's partition order)."""
+    """dim % 256 != 0: behind the end of a row's partial last chunk the LDS ring holds whatever an earlier chunk left there
+    (the DMA lanes behind the end move nothing); the waves whose columns lie past the row skip their matrix instructions and
+    the wave the row ends in clears the units behind the end, so a NaN row (a zero embedding: 0/0, as in the reference) must
+    not turn any other row into NaN.  The NaN row itself ranks first for every query (NumPy's partition order)."""
     from dewi import _engine as eng
     import torch
     n, k, b = 70_000, 5, 16

@@ -128,7 +128,8 @@ def test_large_merge_carries_the_refusal_marker_and_rejects_a_short_workspace():
 
 
 @pytest.mark.parametrize("dim,k,b,qscale", [(768, 10, 33, 1.0), (512, 50, 8, 1.0), (256, 128, 40, 1.0), (768, 10, 12, 20.0),
-                                            (384, 10, 12, 1.0), (640, 50, 33, 1.0), (160, 10, 6, 1.0)])      # round 4: partial last chunk
+                                            (384, 10, 12, 1.0), (640, 50, 33, 1.0), (160, 10, 6, 1.0),       # round 4: partial last chunk
+                                            (300, 10, 12, 1.0), (132, 10, 33, 1.0), (700, 50, 8, 1.0)])      # ... that ends inside a wave's slice
 def test_l2_exact_refine_equals_the_one_query_search(dim, k, b, qscale):
     """l2 batches over an fp32 corpus run on the matrix cores in exact-refine mode: the pass's score has an absolute error
     bound, the candidate cut is widened by it and the candidates are re-scored with the row kernels' arithmetic — so a
@@ -490,7 +491,9 @@ def test_bf16_dim768_shards_are_bit_equal_on_even_boundaries():
                                        # 384 / 640 with more than 32 queries = the 256-query pass; otherwise the depth-split pass with a
                                        # partial last chunk over the shadow
                                        (384, 70_000, 256, 10), (384, 66_000, 12, 50), (640, 66_001, 40, 10), (160, 80_000, 33, 10),
-                                       (992, 66_000, 8, 10), (1280, 65_600, 5, 20)])
+                                       (992, 66_000, 8, 10), (1280, 65_600, 5, 20),
+                                       # ... dim % 8 == 0 from 136 columns: rows that end inside a wave's 32-column slice
+                                       (200, 70_000, 12, 10), (1000, 65_600, 33, 10), (136, 66_000, 5, 10), (264, 66_000, 40, 20)])
 def test_fp32_corpus_with_bf16_shadow_equals_the_one_query_search(dim, n, b, k):
     """fp32 corpus + bf16 shadow (dewi_knn_rerank_f32_shadow): a batch of cosine queries runs a matrix-core pass over the
     shadow as a pre-selection (2-32 queries: the depth-split pass in its bf16 geometry; more: the 256-query pass) and
@@ -523,7 +526,8 @@ def test_fp32_corpus_with_bf16_shadow_equals_the_one_query_search(dim, n, b, k):
 
 @pytest.mark.parametrize("dim,n,k", [(768, 70_000, 10), (256, 131_073, 128), (512, 66_000, 1), (768, 80_001, 16), (256, 70_000, 17),
                                      (1024, 70_000, 10), (1024, 66_000, 64), (1536, 70_000, 10),
-                                     (384, 70_000, 10), (640, 66_000, 40)])          # round 4: the depth-split pass, partial last chunk
+                                     (384, 70_000, 10), (640, 66_000, 40),           # round 4: the depth-split pass, partial last chunk
+                                     (200, 70_000, 10), (1000, 66_000, 40)])         # ... dim % 8 == 0, not % 32
 def test_one_query_through_the_bf16_shadow_equals_the_fp32_row_scan(dim, n, k):
     """enable_bf16_shadow(single_query=True): ONE query runs a pass over the shadow — cuts of up to 32 rows (k <= 16) the bf16 row
     kernel with per-workgroup lists long enough for the error band, larger cuts the depth-split pass — + the exact re-scoring;
