@@ -572,7 +572,12 @@ int dewi_knn_scan_kernel(int elem_type, int64_t n_rows, int dim, int n_queries, 
     const int nq = n_queries >= p.nq_max ? p.nq_max : 1;
     switch (p.kind) {
       case dewi::kScanFast: snprintf(out, out_bytes, "scan_rows_%s", e); break;
-      case dewi::kScanAnyLong: snprintf(out, out_bytes, "scan_rows_any<%d, %d, %d, %d, %d, %d, %s>", elem_type ? 1 : 0, p.u_pad,
+      case dewi::kScanAnyLong:
+        if (p.odd_contig && nq == 1) {
+          snprintf(out, out_bytes, "scan_rows_odd_contig<%d, %d, %d, %d, %d>", elem_type ? 1 : 0, p.u_pad, p.odd_contig_rows, space, p.slots);
+          break;
+        }
+        snprintf(out, out_bytes, "scan_rows_any<%d, %d, %d, %d, %d, %d, %s>", elem_type ? 1 : 0, p.u_pad,
                                         nq > 1 ? p.rows_per_iter_batch : p.rows_per_iter, nq, space, p.slots,
                                         p.odd_rows ? "true" : "false"); break;
       case dewi::kScanAnyShort: snprintf(out, out_bytes, "scan_short_rows_any<%d, %d, %d, %d, %d, %s>", elem_type ? 1 : 0,

@@ -402,6 +402,8 @@ ScanPlan plan_scan(int64_t n_rows, int dim, int elem_bytes, int n_candidates, in
   // rows that are NOT whole units (round 4; they used to take scan_generic_*): the same two kernels in their PH form —
   // aligned 16-byte loads, each wave / lane group on the rows of one residue mod G = 16 / gcd(16, row bytes)
   p.odd_rows = false;
+  p.odd_contig = false;
+  p.odd_contig_rows = 0;
   p.row_cols = dim;
   if (!p.fast && dim % cols_per_unit != 0) {
     const int row_bytes = dim * elem_bytes;
@@ -434,6 +436,12 @@ ScanPlan plan_scan(int64_t n_rows, int dim, int elem_bytes, int n_candidates, in
       p.level = tuning.rows_per_iter > 0 ? (tuning.rows_per_iter - 1) % kAnyLevels : level;
       p.rows_per_iter = any_rows(p.u_pad, 1, p.level);
       p.rows_per_iter_batch = any_rows(p.u_pad, p.nq_max, p.level);
+      // narrow rows whose offsets repeat every 2 or 4 rows: one query runs with a wave on consecutive rows (scan_any.hpp)
+      if (p.u_pad <= 2 && period <= kOddPeriod && tuning.rows_per_iter == 0) {
+        p.odd_contig = true;
+        p.odd_contig_rows = odd_contig_rows(p.u_pad, p.rows_per_iter);
+        p.rows_per_iter = p.odd_contig_rows;
+      }
     }
   }
   p.raw_queries = p.kind != kScanGeneric;

@@ -68,6 +68,9 @@ struct ScanPlan {
   int level;          // kScanAnyLong: which rows-in-flight choice of its units-per-lane count (scan_any.hpp any_level / any_rows)
   bool odd_rows;      // any-width kernels: rows are NOT whole 16-byte units (fp32: dim % 4, bf16: dim % 8) — the PH = true kernels
   int row_cols;       // odd_rows: columns per row (what those kernels take instead of `units`; `units` is then the most a row touches)
+  bool odd_contig;    // odd_rows, kScanAnyLong, at most two units per lane, offsets repeating every 2 or 4 rows: ONE query takes
+                      // scan_rows_odd_contig (a wave on consecutive rows), odd_contig_rows rows per step
+  int odd_contig_rows;
   int nq_max;         // most queries one corpus pass of the row kernel serves besides 1 (4; 2 or 1 for wide rows: scan_any.hpp any_nq_max)
   bool raw_queries;   // the kernel normalises the raw queries itself (everything but kScanGeneric)
   int64_t keys_per_query;  // number of uint64 keys the scan emits per query

@@ -322,6 +322,118 @@ __global__ __launch_bounds__(kScanThreads) void scan_rows_any(const u32x4* __res
   scan_rows_any_body<ELEM, U, R, NQ, SPACE, S, PH>(E, n_rows, units, Q, n_candidates, keys, keys_per_query, merge_buf);
 }
 
+// Rows that are not whole units, ONE query, up to two units per lane: a wave on CONSECUTIVE rows (scan_rows_odd_contig).
+// The per-residue form above gives neighbouring rows to different waves, so every cache line two rows share is requested by
+// two waves; with nontemporal loads more than half of the second requests went back to HBM (FETCH_SIZE x 2 at dim 301:
+// 1.063 x the corpus; plain loads kept them cached but streamed slower).  Narrow rows can afford the other layout: the wave
+// keeps one register set of query fragments and masks PER RESIDUE (kOddPeriod x U x 8 registers) and takes R consecutive rows
+// per step, R a multiple of the period, so that row i of a step always has residue i mod period — a compile-time choice of
+// the register set.  Same loads, same lanes, same sums per row as the per-residue form (a row's offset inside its first unit
+// is a property of its address): results are bit-equal, shards included.
+constexpr int kOddPeriod = 4;   // serves offsets that repeat every 2 or 4 rows (every fp32 width; bf16 rows with a period of 8 keep the per-residue form)
+template <int ELEM, int U, int R, int SPACE, int S>
+__global__ __launch_bounds__(kScanThreads) void scan_rows_odd_contig(const u32x4* __restrict__ E, int64_t n_rows, int dim,
+                                                                     const float* __restrict__ Q, int n_candidates,
+                                                                     uint64_t* __restrict__ keys, int64_t keys_per_query) {
+  static_assert(R % kOddPeriod == 0, "a step's rows must cover whole periods");
+  constexpr int G = kOddPeriod;
+  constexpr int kCols = ELEM ? 8 : 4;
+  constexpr int kElemBytes = ELEM ? 2 : 4;
+  constexpr bool DENSE = S == 0;
+  __shared__ MergeShared merge_buf;
+  const int lane = lane_id();
+  const int wave_in_block = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  const int64_t gwave = static_cast<int64_t>(blockIdx.x) * (kScanThreads / kWave) + wave_in_block;
+  const int64_t n_waves = static_cast<int64_t>(gridDim.x) * (kScanThreads / kWave);
+  const int off0 = static_cast<int>(reinterpret_cast<uintptr_t>(E) & 15u);
+  E = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(E) - off0);
+  const int row_bytes = dim * kElemBytes;
+
+  // per residue g (rows g, g + G, ...): the units a row touches, the row's own columns in each of them, the query fragments
+  bool act[G][U];
+  u32x4 keep[G][U];
+  UnitFrag<ELEM, SPACE> qf[G][U];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int head = (off0 + g * row_bytes) & 15;
+    const int head_el = head / kElemBytes;
+    const int units = (head + row_bytes + 15) >> 4;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      act[g][u] = lane + 64 * u < units;
+      keep[g][u] = unit_keep_mask<ELEM>((lane + 64 * u) * kCols - head_el, dim);
+      qf[g][u].load_shifted(Q, (lane + 64 * u) * kCols - head_el, dim);
+    }
+  }
+  if constexpr (SPACE == DEWI_SPACE_COSINE) {
+    const float norm = wave_query_norm(strided_sumsq(Q, dim, lane));
+    if (norm > 0.f) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) qf[g][u].scale(norm);
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) qf[g][u].finish();
+  }
+
+  WaveList<DENSE ? 1 : S> lst;
+  if constexpr (!DENSE) lst.init(n_candidates, lane);
+
+  auto fetch = [&](u32x4(&v)[U], int64_t row, const bool(&a)[U]) {
+    const u32x4* p = E + ((off0 + row * row_bytes) >> 4) + lane;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      v[u] = u32x4{0u, 0u, 0u, 0u};
+      if (a[u]) v[u] = load_u4<true>(p + 64 * u);
+    }
+  };
+  auto consume = [&](const u32x4(&v)[U], int64_t row, const u32x4(&k)[U], const UnitFrag<ELEM, SPACE>(&q)[U]) {
+    float acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc = q[u].dot(and_u4(v[u], k[u]), acc);
+    float s = wave_sum_f32(acc);
+    if constexpr (SPACE == DEWI_SPACE_L2) s = -s;
+    if constexpr (DENSE) {
+      if (lane == 0) keys[row] = make_key(s, static_cast<uint32_t>(row));
+    } else {
+      lst.offer(s, static_cast<uint32_t>(row), lane);
+    }
+  };
+
+  const int64_t n_groups = n_rows / R;
+  for (int64_t grp = gwave; grp < n_groups; grp += n_waves) {
+    u32x4 v[R][U];
+#pragma unroll
+    for (int r = 0; r < R; ++r) fetch(v[r], grp * R + r, act[r % G]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) consume(v[r], grp * R + r, keep[r % G], qf[r % G]);
+  }
+  for (int64_t row = n_groups * R + gwave; row < n_rows; row += n_waves) {   // fewer than R rows left: residue at run time
+    const int g_row = static_cast<int>(row & (G - 1));                       // (n_groups * R is a multiple of G)
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (g_row == g) {
+        u32x4 v[U];
+        fetch(v, row, act[g]);
+        consume(v, row, keep[g], qf[g]);
+      }
+    }
+  }
+
+  if constexpr (S == 1) {
+    block_merge_store(lst, merge_buf, keys + static_cast<int64_t>(blockIdx.x) * n_candidates, n_candidates, lane, wave_in_block);
+  } else if constexpr (!DENSE) {
+    lst.store(keys + gwave * n_candidates, n_candidates, lane);
+  }
+}
+// rows per step of that kernel (multiples of kOddPeriod), from the rows-in-flight choice of the per-residue form
+constexpr int odd_contig_rows(int u, int rows_any) { return u == 1 ? (rows_any >= 12 ? 12 : 8) : (rows_any >= 6 ? 8 : 4); }
+
 // REPAIR form: every flagged query of a batch, one corpus pass each, in one launch (knn_scan.hip scan_rows_f32_flagged)
 template <int ELEM, int U, int R, int SPACE, int S>
 __global__ __launch_bounds__(kScanThreads) void scan_rows_any_flagged(const u32x4* __restrict__ E, int64_t n_rows, int units,
@@ -569,6 +681,32 @@ static hipError_t launch_scan_any_impl(const ScanPlan& plan, const void* d_E, in
     DEWI_ANY_S(NQ, DEWI_SPACE_COSINE)  \
   } else {                             \
     DEWI_ANY_S(NQ, DEWI_SPACE_L2)      \
+  }
+  if constexpr (PH) {
+    if (nq == 1 && plan.odd_contig) {   // narrow rows, one query: a wave on consecutive rows (scan_rows_odd_contig)
+#define DEWI_ODD_CONTIG(UU, RR, SPACE)                                                                                              \
+  switch (plan.slots) {                                                                                                             \
+    case 0: hipLaunchKernelGGL((scan_rows_odd_contig<ELEM, UU, RR, SPACE, 0>), dim3(plan.blocks), dim3(kScanThreads), 0, stream, E,  \
+                               n_rows, dim, Q, n_candidates, keys, plan.keys_per_query); break;                                      \
+    case 1: hipLaunchKernelGGL((scan_rows_odd_contig<ELEM, UU, RR, SPACE, 1>), dim3(plan.blocks), dim3(kScanThreads), 0, stream, E,  \
+                               n_rows, dim, Q, n_candidates, keys, plan.keys_per_query); break;                                      \
+    default: hipLaunchKernelGGL((scan_rows_odd_contig<ELEM, UU, RR, SPACE, kMaxSlots>), dim3(plan.blocks), dim3(kScanThreads), 0,    \
+                                stream, E, n_rows, dim, Q, n_candidates, keys, plan.keys_per_query); break;                          \
+  }                                                                                                                                 \
+  return hipGetLastError();
+#define DEWI_ODD_CONTIG_R(UU, RR)                                       \
+  if (plan.u_pad == UU && plan.odd_contig_rows == RR) {                  \
+    if (space == DEWI_SPACE_COSINE) { DEWI_ODD_CONTIG(UU, RR, DEWI_SPACE_COSINE) } \
+    else { DEWI_ODD_CONTIG(UU, RR, DEWI_SPACE_L2) }                      \
+  }
+      DEWI_ODD_CONTIG_R(1, 12)
+      DEWI_ODD_CONTIG_R(1, 8)
+      DEWI_ODD_CONTIG_R(2, 8)
+      DEWI_ODD_CONTIG_R(2, 4)
+#undef DEWI_ODD_CONTIG_R
+#undef DEWI_ODD_CONTIG
+      return hipErrorInvalidValue;
+    }
   }
   if (nq == 1) {
     DEWI_ANY_Q(1)

@@ -81,7 +81,7 @@ probe_pmc WRITE_SIZE_bf16b32 WRITE_SIZE --bf16 32
 python3 scripts/summarize_pmc.py $OUT --commit $COMMIT --record "1000000x768x4xB1=scan_rows_f32" "1000000x768x2xB256=mfma_scan_bf16_s16<48, false>" \
   "6000000x128x4xB1=scan_short_rows_any<0, 8, 1, 0, 1, false>" "2000000x384x4xB1=scan_rows_any<0, 2, 3, 1, 0, 1, false>" "768000x1000x4xB1=scan_rows_any<0, 4, 1, 1, 0, 1, false>" \
   "600000x1280x4xB1=scan_rows_any<0, 5, 1, 1, 0, 1, false>" "250000x3072x4xB1=scan_rows_any<0, 12, 1, 1, 0, 1, false>" \
-  "2551495x301x4xB1=scan_rows_any<0, 2, 6, 1, 0, 1, true>" "767232x1001x4xB1=scan_rows_any<0, 4, 2, 1, 0, 1, true>" \
+  "2551495x301x4xB1=scan_rows_odd_contig<0, 2, 8, 0, 1>" "767232x1001x4xB1=scan_rows_any<0, 4, 2, 1, 0, 1, true>" \
   "1000000x768x4xB32=mfma_scan_f32<false, 3, false, false, false>" "1000000x768x2xB32=mfma_scan_f32<true, 3, false, false, false>" \
   "1000000x768x2xB1=scan_rows_bf16<3, 1, 0, 1, true>" \
   "rowcos_1000000x512=row_cosine_512_kernel<2>" "fit_med_7x1000000=fit_fast_kernel<false>" "fit_mad_7x1000000=fit_fast_kernel<true>" > $OUT/pmc_summary.txt

@@ -4,7 +4,8 @@ through the C ABI.
 The reference scores any width with one BLAS call (src/dewi/backends.py:431-436).  Here such rows take the PH = true forms of
 the any-width kernels (csrc/scan_any.hpp): aligned 16-byte loads, every wave / lane group on the rows of one residue mod
 G = 16 / gcd(16, row bytes), the query fragments shifted by that residue's offset, the neighbouring rows' columns in a row's
-first and last unit masked off.  What can go wrong there and nowhere else: a wrong shift for one residue, a neighbour's
+first and last unit masked off (narrow rows with one query: a wave on consecutive rows with a register set of fragments per
+residue, scan_rows_odd_contig).  What can go wrong there and nowhere else: a wrong shift for one residue, a neighbour's
 columns leaking into a sum (NaN / huge neighbours), the first and the last row of the buffer, shards whose first row does not
 start on a unit, fewer rows than residues.
 """
@@ -37,7 +38,8 @@ def _kernel(c, b, k):
 def _expect_odd_kernel(c, dim, limit):
     name = _kernel(c, 1, 10)
     if dim <= limit:
-        assert name.endswith("true>") and "any<" in name, name      # the PH = true form, not scan_generic_*
+        # the PH = true form (or, narrow rows with one query, its consecutive-rows variant), not scan_generic_*
+        assert (name.endswith("true>") and "any<" in name) or name.startswith("scan_rows_odd_contig<"), name
     else:
         assert name.startswith("scan_generic"), name
 
@@ -69,7 +71,7 @@ def test_tiny_odd_widths_fp32(dim):
     dewi32, ent32 = orc.payload_soa(cols["dewi"], cols["ht_mean"], cols["hi_mean"])
     for space in ("cosine", "l2"):
         c = _eng().DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"], space)
-        assert _kernel(c, 1, 10).endswith("true>")
+        assert _kernel(c, 1, 10).endswith("true>")       # (rows shorter than a unit: lanes sharing a row)
         E = c.emb.cpu().numpy()
         for k in (1, 10, 150):
             ids, sc = c.search(Q, k, 0.3, 0.0)
@@ -148,7 +150,7 @@ def test_neighbour_rows_do_not_leak(dim, bf16):
         dirty = eng.DeviceCorpus.from_host(bad, cols["dewi"], cols["ht_mean"], cols["hi_mean"], space)
         if bf16:
             clean, dirty = clean.to_bf16(), dirty.to_bf16()
-        assert _kernel(dirty, 1, 10).endswith("true>")
+        assert _kernel(dirty, 1, 10).endswith("true>") or _kernel(dirty, 1, 10).startswith("scan_rows_odd_contig<")
         k = n                                              # every row's score comes back (eta = 0: score == similarity)
         ids_c, sc_c = clean.search(Q, k, 0.0, 0.0)
         ids_d, sc_d = dirty.search(Q, k, 0.0, 0.0)
@@ -163,7 +165,33 @@ def test_neighbour_rows_do_not_leak(dim, bf16):
                     assert by_id_d[r] == by_id_c[r], (space, j, r, by_id_d[r], by_id_c[r])
 
 
-@pytest.mark.parametrize("dim,bf16", [(5, False), (30, False), (101, False), (1001, False), (9, True), (100, True), (301, True)])
+@pytest.mark.parametrize("dim,bf16", [(129, False), (255, False), (301, False), (387, False), (300, True), (250, True)])
+def test_consecutive_rows_form_equals_the_per_residue_form(dim, bf16):
+    """Narrow odd rows: ONE query runs with a wave on consecutive rows (scan_rows_odd_contig, a register set of query fragments
+    per residue), four queries per pass with a wave per residue (scan_rows_any<..., true>).  Same loads, same lanes, same
+    order of additions per row: the two forms must agree bit for bit — ids and scores, every list shape, both spaces."""
+    eng = _eng()
+    n = 5003
+    rs = np.random.RandomState(dim)
+    raw = rs.randn(n, dim).astype(np.float32)
+    cols = orc.synth_payload_columns(n, seed=dim)
+    Q = rs.randn(4, dim).astype(np.float32)
+    for space in ("cosine", "l2"):
+        c = eng.DeviceCorpus.from_host(raw, cols["dewi"], cols["ht_mean"], cols["hi_mean"], space)
+        if bf16:
+            c = c.to_bf16()
+        assert _kernel(c, 1, 10).startswith("scan_rows_odd_contig<")
+        four_ways = bf16 and space == "l2"                # (bf16 l2 serves four queries as four one-query launches)
+        assert four_ways or ("any<" in _kernel(c, 4, 10) and ", 4, " in _kernel(c, 4, 10)), _kernel(c, 4, 10)
+        for k in (10, 100, 150):                             # one list per workgroup, per wave, dense keys
+            ids4, sc4 = c.search(Q, k, 0.3, 0.1)
+            for j in range(4):
+                ids1, sc1 = c.search(Q[j], k, 0.3, 0.1)
+                assert np.array_equal(ids1[0], ids4[j]) and np.array_equal(sc1[0], sc4[j]), (space, k, j)
+
+
+@pytest.mark.parametrize("dim,bf16", [(5, False), (30, False), (101, False), (129, False), (301, False), (1001, False), (9, True), (100, True),
+                                       (301, True)])
 def test_odd_width_shards_equal_the_whole(dim, bf16):
     """Shards are views into the same buffer: their first row starts anywhere inside a unit.  A row's offset inside its first
     unit is a property of its ADDRESS, so the same lanes sum the same columns in the shard and in the whole: bit-equal."""
